@@ -1,0 +1,280 @@
+"""ctypes binding of the C ABI declared in include/dqmc_hip.h.
+
+The binder is generic over (shared-library path, symbol prefix) because the
+CPU oracle exports the same function set with prefix ``orc_`` (see
+oracle/__init__.py -- test infrastructure only).  The product instance, bound
+to ``dqmc_amd/libdqmc_hip.so`` with prefix ``dqmc_``, is created by
+``dqmc_amd.lib()`` and fails loudly when the HIP library is missing or no GPU
+is present: there is no fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Tuple
+
+import numpy as np
+
+c_double_p = C.POINTER(C.c_double)
+c_int64_p = C.POINTER(C.c_int64)
+c_int32_p = C.POINTER(C.c_int32)
+c_uint8_p = C.POINTER(C.c_uint8)
+
+
+class Stats(C.Structure):
+    """dqmc_stats of include/dqmc_hip.h."""
+    _fields_ = [("acc_rate", C.c_double), ("max_err", C.c_double), ("sum_err", C.c_double),
+                ("n_err", C.c_double), ("n_accepted", C.c_int64), ("n_proposed", C.c_int64)]
+
+    @property
+    def mean_err(self) -> float:            # DQMC::mean_err(), include/dqmc.h:80
+        return self.sum_err / self.n_err if self.n_err else 0.0
+
+
+class DqmcError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"[{code}] {msg}")
+        self.code = code
+
+
+# every symbol include/dqmc_hip.h declares (without prefix): the CPU test
+# `test_abi_exports` checks the built library exports each of them.
+ABI_SYMBOLS = [
+    "last_error", "backend", "device_count",
+    "to_ldr", "ldr_mul_mat", "mat_mul_ldr", "ldr_mul_ldr", "inv_I_plus_ldr", "inv_I_plus_ldr_mul_ldr",
+    "gemm", "rank1_update",
+    "create", "destroy", "set_fields", "get_fields", "init", "get_G", "set_G", "get_logdet",
+    "n_stack", "get_stack", "sweep_0_to_beta", "sweep_beta_to_0", "sync", "get_stats",
+    "wrap_forward", "wrap_backward", "local_update_slice", "calculate_Bbar", "global_action",
+    "update_kernel_time", "set_profiling",
+]
+
+
+def _f64(a) -> np.ndarray:
+    """Column-major (Fortran) contiguous float64 copy/view."""
+    return np.asfortranarray(a, dtype=np.float64)
+
+
+def _p(a: np.ndarray):
+    return a.ctypes.data_as(c_double_p)
+
+
+class DqmcLib:
+    """One loaded shared library exposing <prefix>* of include/dqmc_hip.h."""
+
+    def __init__(self, path: str, prefix: str):
+        if not os.path.exists(path):
+            raise FileNotFoundError(
+                f"{path} not found: build it first (python -c 'import __graft_entry__ as g; g.build()' or make)")
+        self.path, self.prefix = path, prefix
+        self._dll = C.CDLL(path, mode=C.RTLD_GLOBAL)
+        g = self._sym
+        g("last_error").restype = C.c_char_p
+        g("backend").restype = C.c_char_p
+        g("destroy").restype = None
+        g("destroy").argtypes = [C.c_void_p]
+        for name in ("set_fields", "get_fields"):
+            g(name).argtypes = [C.c_void_p, c_int64_p]
+        for name in ("init", "sync", "n_stack"):
+            g(name).argtypes = [C.c_void_p]
+        g("create").argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
+                                c_double_p, c_double_p, c_double_p, c_double_p]
+        for name in ("get_G", "set_G", "get_logdet", "global_action"):
+            g(name).argtypes = [C.c_void_p, c_double_p]
+        g("get_stack").argtypes = [C.c_void_p, C.c_int, c_double_p, c_double_p, c_double_p]
+        for name in ("sweep_0_to_beta", "sweep_beta_to_0"):
+            g(name).argtypes = [C.c_void_p, c_int32_p, c_uint8_p, c_double_p]
+        g("get_stats").argtypes = [C.c_void_p, C.POINTER(Stats)]
+        for name in ("wrap_forward", "wrap_backward"):
+            g(name).argtypes = [C.c_void_p, C.c_int]
+        g("local_update_slice").argtypes = [C.c_void_p, C.c_int, c_int32_p, c_uint8_p, c_double_p, C.POINTER(C.c_int)]
+        g("calculate_Bbar").argtypes = [C.c_void_p, C.c_int, c_double_p]
+        g("update_kernel_time").argtypes = [C.c_void_p, c_double_p, c_int64_p, c_int64_p]
+        g("set_profiling").argtypes = [C.c_void_p, C.c_int]
+        g("to_ldr").argtypes = [C.c_int] + [c_double_p] * 4
+        g("ldr_mul_mat").argtypes = [C.c_int] + [c_double_p] * 7
+        g("mat_mul_ldr").argtypes = [C.c_int] + [c_double_p] * 7
+        g("ldr_mul_ldr").argtypes = [C.c_int] + [c_double_p] * 9
+        g("inv_I_plus_ldr").argtypes = [C.c_int] + [c_double_p] * 5
+        g("inv_I_plus_ldr_mul_ldr").argtypes = [C.c_int] + [c_double_p] * 7
+        g("gemm").argtypes = [C.c_int, c_double_p, C.c_int, c_double_p, C.c_int, c_double_p]
+        g("rank1_update").argtypes = [C.c_int, c_double_p, C.c_int, C.c_double]
+
+    def _sym(self, name: str):
+        return getattr(self._dll, self.prefix + name)
+
+    def has_symbol(self, name: str) -> bool:
+        return hasattr(self._dll, self.prefix + name)
+
+    def check(self, rc: int):
+        if rc != 0:
+            raise DqmcError(rc, (self._sym("last_error")() or b"").decode())
+
+    # -- misc -----------------------------------------------------------
+    def backend(self) -> str:
+        return self._sym("backend")().decode()
+
+    def device_count(self) -> int:
+        return int(self._sym("device_count")())
+
+    # -- stateless stable linear algebra (include/stablelinalg.h:36-46) --
+    def to_ldr(self, M) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+        M = _f64(M); n = M.shape[0]
+        L, d, R = np.empty((n, n), order="F"), np.empty(n), np.empty((n, n), order="F")
+        self.check(self._sym("to_ldr")(n, _p(M), _p(L), _p(d), _p(R)))
+        return L, d, R
+
+    def ldr_mul_mat(self, F, M):
+        L, d, R = (_f64(x) for x in F); M = _f64(M); n = M.shape[0]
+        Lo, do, Ro = np.empty((n, n), order="F"), np.empty(n), np.empty((n, n), order="F")
+        self.check(self._sym("ldr_mul_mat")(n, _p(L), _p(d), _p(R), _p(M), _p(Lo), _p(do), _p(Ro)))
+        return Lo, do, Ro
+
+    def mat_mul_ldr(self, M, F):
+        L, d, R = (_f64(x) for x in F); M = _f64(M); n = M.shape[0]
+        Lo, do, Ro = np.empty((n, n), order="F"), np.empty(n), np.empty((n, n), order="F")
+        self.check(self._sym("mat_mul_ldr")(n, _p(M), _p(L), _p(d), _p(R), _p(Lo), _p(do), _p(Ro)))
+        return Lo, do, Ro
+
+    def ldr_mul_ldr(self, F1, F2):
+        L1, d1, R1 = (_f64(x) for x in F1); L2, d2, R2 = (_f64(x) for x in F2); n = L1.shape[0]
+        Lo, do, Ro = np.empty((n, n), order="F"), np.empty(n), np.empty((n, n), order="F")
+        self.check(self._sym("ldr_mul_ldr")(n, _p(L1), _p(d1), _p(R1), _p(L2), _p(d2), _p(R2), _p(Lo), _p(do), _p(Ro)))
+        return Lo, do, Ro
+
+    def inv_I_plus_ldr(self, F) -> Tuple[np.ndarray, float]:
+        L, d, R = (_f64(x) for x in F); n = L.shape[0]
+        G = np.empty((n, n), order="F"); ld = C.c_double(0.0)
+        self.check(self._sym("inv_I_plus_ldr")(n, _p(L), _p(d), _p(R), _p(G), C.byref(ld)))
+        return G, ld.value
+
+    def inv_I_plus_ldr_mul_ldr(self, F1, F2) -> np.ndarray:
+        L1, d1, R1 = (_f64(x) for x in F1); L2, d2, R2 = (_f64(x) for x in F2); n = L1.shape[0]
+        G = np.empty((n, n), order="F")
+        self.check(self._sym("inv_I_plus_ldr_mul_ldr")(n, _p(L1), _p(d1), _p(R1), _p(L2), _p(d2), _p(R2), _p(G)))
+        return G
+
+    def gemm(self, A, B, transA: bool = False, transB: bool = False) -> np.ndarray:
+        A = _f64(A); B = _f64(B); n = A.shape[0]
+        Cm = np.empty((n, n), order="F")
+        self.check(self._sym("gemm")(n, _p(A), int(transA), _p(B), int(transB), _p(Cm)))
+        return Cm
+
+    def rank1_update(self, G, i: int, delta: float) -> np.ndarray:
+        G = np.array(G, dtype=np.float64, order="F", copy=True); n = G.shape[0]
+        self.check(self._sym("rank1_update")(n, _p(G), int(i), float(delta)))
+        return G
+
+    def engine(self, *args, **kw) -> "Engine":
+        return Engine(self, *args, **kw)
+
+
+class Engine:
+    """Handle onto one dqmc_engine (one Markov chain): class DQMC of the
+    reference (include/dqmc.h:21-93) with the model/field state it reads."""
+
+    def __init__(self, lib: DqmcLib, n_sites: int, nt: int, n_stab: int, g: float, gamma, eta,
+                 expK, invexpK, device: int = 0):
+        self.lib, self.n, self.nt, self.n_stab = lib, int(n_sites), int(nt), int(n_stab)
+        gamma = np.ascontiguousarray(gamma, dtype=np.float64); eta = np.ascontiguousarray(eta, dtype=np.float64)
+        eK, iK = _f64(expK), _f64(invexpK)
+        assert eK.shape == (self.n, self.n) and iK.shape == (self.n, self.n)
+        h = C.c_void_p()
+        lib.check(lib._sym("create")(C.byref(h), device, self.n, self.nt, self.n_stab, float(g),
+                                     _p(gamma), _p(eta), _p(eK), _p(iK)))
+        self._h: Optional[C.c_void_p] = h
+
+    def close(self):
+        if self._h is not None:
+            self.lib._sym("destroy")(self._h); self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _c(self, name, *args):
+        self.lib.check(self.lib._sym(name)(self._h, *args))
+
+    # fields cross the ABI as arma::imat memory: nt x nv column-major int64
+    def set_fields(self, fields):
+        """fields: integer array of shape (nt, n_sites), values in {0,1,2,3}."""
+        f = np.asfortranarray(np.asarray(fields).reshape(self.nt, self.n), dtype=np.int64)
+        self._c("set_fields", f.ctypes.data_as(c_int64_p))
+
+    def get_fields(self) -> np.ndarray:
+        f = np.empty((self.nt, self.n), dtype=np.int64, order="F")
+        self._c("get_fields", f.ctypes.data_as(c_int64_p)); return f
+
+    def init(self):
+        self._c("init")
+
+    def get_G(self) -> np.ndarray:
+        G = np.empty((self.n, self.n), order="F"); self._c("get_G", _p(G)); return G
+
+    def set_G(self, G):
+        G = _f64(G); self._c("set_G", _p(G))
+
+    def get_logdet(self) -> float:
+        v = C.c_double(0.0); self._c("get_logdet", C.cast(C.byref(v), c_double_p)); return v.value
+
+    def n_stack(self) -> int:
+        return int(self.lib._sym("n_stack")(self._h))
+
+    def get_stack(self, i: int):
+        n = self.n
+        L, d, R = np.empty((n, n), order="F"), np.empty(n), np.empty((n, n), order="F")
+        self._c("get_stack", int(i), _p(L), _p(d), _p(R)); return L, d, R
+
+    def _stream(self, perm, kprop, u, rows):
+        perm = np.ascontiguousarray(np.asarray(perm).reshape(rows, self.n), dtype=np.int32)
+        kprop = np.ascontiguousarray(np.asarray(kprop).reshape(rows, self.n), dtype=np.uint8)
+        u = np.ascontiguousarray(np.asarray(u).reshape(rows, self.n), dtype=np.float64)
+        return perm, kprop, u
+
+    def sweep_0_to_beta(self, perm, kprop, u):
+        perm, kprop, u = self._stream(perm, kprop, u, self.nt)
+        self._c("sweep_0_to_beta", perm.ctypes.data_as(c_int32_p), kprop.ctypes.data_as(c_uint8_p), _p(u))
+
+    def sweep_beta_to_0(self, perm, kprop, u):
+        perm, kprop, u = self._stream(perm, kprop, u, self.nt)
+        self._c("sweep_beta_to_0", perm.ctypes.data_as(c_int32_p), kprop.ctypes.data_as(c_uint8_p), _p(u))
+
+    def sync(self):
+        self._c("sync")
+
+    def stats(self) -> Stats:
+        s = Stats(); self._c("get_stats", C.byref(s)); return s
+
+    def wrap_forward(self, l: int):
+        self._c("wrap_forward", int(l))
+
+    def wrap_backward(self, l: int):
+        self._c("wrap_backward", int(l))
+
+    def local_update_slice(self, l: int, perm, kprop, u) -> int:
+        perm, kprop, u = self._stream(perm, kprop, u, 1)
+        acc = C.c_int(0)
+        self._c("local_update_slice", int(l), perm.ctypes.data_as(c_int32_p), kprop.ctypes.data_as(c_uint8_p), _p(u), C.byref(acc))
+        return acc.value
+
+    def calculate_Bbar(self, i_stack: int) -> np.ndarray:
+        B = np.empty((self.n, self.n), order="F"); self._c("calculate_Bbar", int(i_stack), _p(B)); return B
+
+    def global_action(self) -> float:
+        v = C.c_double(0.0); self._c("global_action", C.cast(C.byref(v), c_double_p)); return v.value
+
+    def set_profiling(self, on: bool):
+        self._c("set_profiling", int(bool(on)))
+
+    def update_kernel_time(self):
+        ms = C.c_double(0.0); nl = C.c_int64(0); na = C.c_int64(0)
+        self._c("update_kernel_time", C.cast(C.byref(ms), c_double_p), C.cast(C.byref(nl), c_int64_p), C.cast(C.byref(na), c_int64_p))
+        return ms.value, nl.value, na.value

@@ -1,0 +1,101 @@
+"""Host-side model constants for the sweep engine (test/bench plumbing).
+
+Mirrors what AttractiveHubbard's constructor derives before the hot path
+starts (source/model.cpp:3-60), GHQField's tables (include/field.h:29-48) and
+Lattice's neighbour rule (include/lattice.h:100-107).  The C++17 facade in
+dqmc_amd/host carries the same logic for C++ callers.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict
+
+import numpy as np
+
+
+def ghq_tables():
+    """gamma, eta of the 4-state Gauss-Hermite HS field (include/field.h:32-43)."""
+    s6 = np.sqrt(6.0)
+    gamma = np.array([1.0 - s6 / 3.0, 1.0 + s6 / 3.0, 1.0 + s6 / 3.0, 1.0 - s6 / 3.0])
+    eta = np.array([-np.sqrt(2.0 * (3.0 + s6)), -np.sqrt(2.0 * (3.0 - s6)),
+                    np.sqrt(2.0 * (3.0 - s6)), np.sqrt(2.0 * (3.0 + s6))])
+    return gamma, eta
+
+
+PROPOSAL = np.array([[1, 2, 3], [0, 2, 3], [0, 1, 3], [0, 1, 2]])   # include/field.h:45-48
+
+
+def build_K(L1: int, L2: int, t: float, mu: float) -> np.ndarray:
+    """AttractiveHubbard::build_K_matrix (source/model.cpp:39-60): assignment
+    (not +=) of -t on +x and +y bonds, site = y*L1 + x, PBC."""
+    n = L1 * L2
+    K = np.zeros((n, n))
+    for i in range(n):
+        K[i, i] = -mu
+        ux, uy = i % L1, i // L1
+        nx = uy * L1 + (ux + 1) % L1
+        ny = ((uy + 1) % L2) * L1 + ux
+        K[i, nx] = -t; K[nx, i] = -t
+        K[i, ny] = -t; K[ny, i] = -t
+    return K
+
+
+def expm_sym(A: np.ndarray) -> np.ndarray:
+    """exp of a real symmetric matrix by eigendecomposition (the reference
+    calls arma::expmat, source/model.cpp:32-35; setup only, not on the path)."""
+    w, V = np.linalg.eigh(A)
+    return (V * np.exp(w)) @ V.T
+
+
+@dataclass
+class HubbardModel:
+    L1: int
+    L2: int
+    U: float
+    beta: float
+    nt: int
+    n_stab: int = 10
+    t: float = 1.0
+    mu: float = -0.1
+    expK: np.ndarray = field(init=False, repr=False)
+    invexpK: np.ndarray = field(init=False, repr=False)
+
+    def __post_init__(self):
+        self.n = self.L1 * self.L2
+        self.dtau = self.beta / self.nt                          # source/model.cpp:23
+        self.g = float(np.sqrt(0.5 * abs(self.U) * self.dtau))   # source/model.cpp:27
+        self.alpha = -1.0
+        self.gamma, self.eta = ghq_tables()
+        self.K = build_K(self.L1, self.L2, self.t, self.mu)
+        self.expK = np.asfortranarray(expm_sym(-self.dtau * self.K))
+        self.invexpK = np.asfortranarray(expm_sym(self.dtau * self.K))
+        self.n_stack = -(-self.nt // self.n_stab)
+
+    def engine(self, lib, device: int = 0):
+        return lib.engine(self.n, self.nt, self.n_stab, self.g, self.gamma, self.eta, self.expK, self.invexpK, device=device)
+
+    def random_fields(self, seed: int) -> np.ndarray:
+        """i.i.d. uniform {0,1,2,3} fields, shape (nt, n) (include/field.h:54-57)."""
+        return np.random.default_rng(seed).integers(0, 4, size=(self.nt, self.n), dtype=np.int64)
+
+    def random_stream(self, rng: np.random.Generator, rows: int = None):
+        """(perm, kprop, u) for `rows` slices (default nt): what one half-sweep of
+        update::local_update consumes (source/update.cpp:10-25)."""
+        rows = self.nt if rows is None else rows
+        perm = np.stack([rng.permutation(self.n) for _ in range(rows)]).astype(np.int32)
+        kprop = rng.integers(0, 3, size=(rows, self.n), dtype=np.uint8)
+        u = rng.random((rows, self.n))
+        return perm, kprop, u
+
+    # plain numpy evaluation of B_l (source/dqmc.cpp:78-80, source/model.cpp:62-72)
+    def B(self, fields_l: np.ndarray) -> np.ndarray:
+        return np.exp(self.g * self.eta[fields_l])[:, None] * self.expK
+
+
+# BASELINE.json configs
+CONFIGS: Dict[str, dict] = {
+    "cfg1": dict(L1=4, L2=4, U=4.0, beta=2.0, nt=20, n_stab=10),
+    "cfg2": dict(L1=8, L2=8, U=4.0, beta=4.0, nt=80, n_stab=10),
+    "cfg3": dict(L1=16, L2=16, U=8.0, beta=8.0, nt=200, n_stab=10),
+    "cfg5": dict(L1=24, L2=24, U=4.0, beta=10.0, nt=400, n_stab=10),
+}

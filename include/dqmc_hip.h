@@ -1,0 +1,195 @@
+/*
+ * dqmc_hip.h -- C ABI of the MI355X-native DQMC equal-time sweep engine.
+ *
+ * This is the drop-in boundary for the hot path named in BASELINE.json
+ * (SURVEY.md section 8): the equal-time Green's-function sweep of kfkq/DQMC.
+ * The reference has no FFI layer (everything is statically linked C++,
+ * CMakeLists.txt:44-53); the entry points below are what a C-ABI binding of
+ * its source-level API for this path would bind.  Each declaration cites the
+ * reference interface it replaces.  INTEGRATION.md shows the reference-side
+ * shim (a replacement source/dqmc.cpp + source/update.cpp body that forwards
+ * to these symbols).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++/torch types.
+ *   - all matrices are column-major fp64 with leading dimension n (Armadillo
+ *     layout, `arma::mat::memptr()`), all host pointers unless stated.
+ *   - HS fields cross the boundary exactly as `arma::imat::memptr()` gives
+ *     them: nt x nv, column-major, 64-bit signed (element (l,i) at l + nt*i;
+ *     include/field.h:21, source/update.cpp:60-69).
+ *   - every function returns 0 on success, a negative DQMC_E* code on
+ *     failure; dqmc_last_error() gives the message for the calling thread.
+ *     The reference throws std::runtime_error / std::out_of_range at the
+ *     same places (source/stablelinalg.cpp:43-45, include/stackngf.h:61-75);
+ *     the C++ facade in dqmc_amd/host rethrows.
+ *   - the library REQUIRES a gfx950 GPU: there is no CPU fallback.  Without
+ *     a device dqmc_create() and every stateless compute call fail with
+ *     DQMC_ENODEVICE.
+ *
+ * The same function set with prefix `orc_` instead of `dqmc_` is exported by
+ * the CPU oracle (oracle/dqmc_oracle.cpp) so the parity tests can drive both
+ * through one harness.  The oracle is test infrastructure only.
+ */
+#ifndef DQMC_HIP_H
+#define DQMC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DQMC_OK         0
+#define DQMC_EINVAL    -1   /* bad argument (shape, index, null pointer)      */
+#define DQMC_ENODEVICE -2   /* no usable gfx950 device / HIP runtime error    */
+#define DQMC_ENUMERIC  -3   /* factorisation broke down (zero pivot / NaN)    */
+#define DQMC_ERANGE    -4   /* stack / slice index out of range               */
+#define DQMC_ENOMEM    -5
+
+typedef struct dqmc_engine dqmc_engine;   /* opaque; one Markov chain on one GPU */
+
+/* Per-engine counters.  acc_rate follows DQMC::acc_rate() (include/dqmc.h:78,
+ * source/dqmc.cpp:366,424: sum over slices of accepted/N/nt, i.e. it grows by
+ * ~a per half-sweep); max_err / mean_err follow DQMC::max_err()/mean_err()
+ * (include/dqmc.h:79-80, source/dqmc.cpp:317-329).                           */
+typedef struct dqmc_stats {
+    double  acc_rate;        /* accumulated like DQMC::acc_rate_               */
+    double  max_err;         /* max wrap-vs-stabilised |dG| since creation     */
+    double  sum_err;         /* total_precision_error_                          */
+    double  n_err;           /* num_cumulated_precision_error_                  */
+    int64_t n_accepted;      /* accepted single-site proposals since creation  */
+    int64_t n_proposed;      /* proposals since creation                        */
+} dqmc_stats;
+
+const char* dqmc_last_error(void);
+/* "hip:gfx950" for the product library, "cpu-oracle:<blas>" for the oracle.  */
+const char* dqmc_backend(void);
+/* number of visible HIP devices (0 when there is none; never fails).          */
+int dqmc_device_count(void);
+
+/* ------------------------------------------------------------------------ *
+ * Stateless stable linear algebra -- include/stablelinalg.h:36-46.
+ * An LDR triple is (L: n*n, d: n, R: n*n).  Host pointers in and out; the
+ * library stages them through HBM on `device` 0 and runs the same kernels the
+ * engine uses.  These exist for parity tests and for callers that use
+ * stablelinalg:: directly.
+ * ------------------------------------------------------------------------ */
+
+/* stablelinalg::to_LDR (source/stablelinalg.cpp:35-55): column-pivoted
+ * Householder QR, M P = Q R0; d = |diag R0|; R = diag(1/d) R0 P^T; L = Q.    */
+int dqmc_to_ldr(int n, const double* M, double* L, double* d, double* R);
+
+/* stablelinalg::ldr_mul_mat (source/stablelinalg.cpp:57-67): F' = F * M.     */
+int dqmc_ldr_mul_mat(int n, const double* L, const double* d, const double* R,
+                     const double* M, double* Lo, double* d_o, double* Ro);
+
+/* stablelinalg::mat_mul_ldr (source/stablelinalg.cpp:69-79): F' = M * F.     */
+int dqmc_mat_mul_ldr(int n, const double* M,
+                     const double* L, const double* d, const double* R,
+                     double* Lo, double* d_o, double* Ro);
+
+/* stablelinalg::ldr_mul_ldr (source/stablelinalg.cpp:81-92): F' = F1 * F2.   */
+int dqmc_ldr_mul_ldr(int n,
+                     const double* L1, const double* d1, const double* R1,
+                     const double* L2, const double* d2, const double* R2,
+                     double* Lo, double* d_o, double* Ro);
+
+/* stablelinalg::inv_I_plus_ldr (source/stablelinalg.cpp:94-126):
+ * G = (I + F)^-1, *logdet = log|det(I + F)|.                                 */
+int dqmc_inv_I_plus_ldr(int n, const double* L, const double* d, const double* R,
+                        double* G, double* logdet);
+
+/* stablelinalg::inv_I_plus_ldr_mul_ldr (source/stablelinalg.cpp:128-158):
+ * G = (I + F1 F2)^-1.                                                        */
+int dqmc_inv_I_plus_ldr_mul_ldr(int n,
+                                const double* L1, const double* d1, const double* R1,
+                                const double* L2, const double* d2, const double* R2,
+                                double* G);
+
+/* Dense C = op(A) op(B) on the fp64 MFMA GEMM kernel (the `*` of
+ * source/dqmc.cpp:76,82,102,130,185).  trans flags: 0 = N, 1 = T.            */
+int dqmc_gemm(int n, const double* A, int transA, const double* B, int transB, double* C);
+
+/* AttractiveHubbard::update_greens_local (source/model.cpp:124-138), one
+ * Sherman-Morrison rank-1 update of a standalone matrix:
+ * G += delta/(1+(1-G_ii) delta) * G[:,i] (G[i,:] - e_i).                     */
+int dqmc_rank1_update(int n, double* G, int i, double delta);
+
+/* ------------------------------------------------------------------------ *
+ * Engine -- class DQMC (include/dqmc.h:21-93) + the model/field state it
+ * reads through AttractiveHubbard& (include/model.h:36-57) and GHQField
+ * (include/field.h:61-83).  State (fields, stack of LDRs, current G) lives
+ * in HBM across calls.
+ * ------------------------------------------------------------------------ */
+
+/* DQMC::DQMC (source/dqmc.cpp:5-36) + the constants AttractiveHubbard's
+ * constructor derives (source/model.cpp:17-35): n_sites = Lattice::n_cells(),
+ * nt, n_stab from [simulation]; g = sqrt(|U| dtau / 2); gamma/eta = GHQField
+ * tables (include/field.h:32-43); expK = expmat(-dtau K), invexpK =
+ * expmat(+dtau K) (n*n column-major).  `device` is the HIP device ordinal.   */
+int dqmc_create(dqmc_engine** out, int device, int n_sites, int nt, int n_stab,
+                double g, const double gamma[4], const double eta[4],
+                const double* expK, const double* invexpK);
+void dqmc_destroy(dqmc_engine* e);
+
+/* GHQField::set_fields / fields() (include/field.h:64,72-74).                */
+int dqmc_set_fields(dqmc_engine* e, const int64_t* fields);
+int dqmc_get_fields(dqmc_engine* e, int64_t* fields);
+
+/* DQMC::init_stacks + DQMC::init_greenfunctions (source/dqmc.cpp:43-72):
+ * rebuilds every stack[i] = B(beta, tau_i) from the current fields and sets
+ * G = Gtt[0] = (I + stack[0])^-1, log_det_M.                                 */
+int dqmc_init(dqmc_engine* e);
+
+/* The equal-time Green's function the sweep currently holds (GF::Gtt[l] of
+ * the slice the sweep front is at; Gtt[0] after init or a full sweep;
+ * include/stackngf.h:15-29) and GF::log_det_M.                               */
+int dqmc_get_G(dqmc_engine* e, double* G);
+int dqmc_set_G(dqmc_engine* e, const double* G);
+int dqmc_get_logdet(dqmc_engine* e, double* logdet);
+
+/* LDRStack::operator[] (include/stackngf.h:60-67).  DQMC_ERANGE mirrors its
+ * std::out_of_range.                                                         */
+int dqmc_n_stack(dqmc_engine* e);
+int dqmc_get_stack(dqmc_engine* e, int i_stack, double* L, double* d, double* R);
+
+/* DQMC::sweep_0_to_beta / sweep_beta_to_0 (source/dqmc.cpp:337-456).
+ * The per-slice random stream that update::local_update draws from
+ * utility::random (source/update.cpp:10-25, include/field.h:76-83,
+ * include/utility.h:34-37) is generated by the HOST caller and passed in,
+ * indexed [l*n_sites + idx] for slice l:
+ *   perm  : the std::shuffle'd site order (source/update.cpp:14)
+ *   kprop : the uniform_int(0,2) proposal index (include/field.h:79-80)
+ *   u     : the canonical uniform that bernoulli(p) compares with p
+ * Calls are asynchronous on the engine's stream; dqmc_get_stats / dqmc_get_G
+ * / dqmc_sync wait for completion.                                           */
+int dqmc_sweep_0_to_beta(dqmc_engine* e, const int32_t* perm, const uint8_t* kprop, const double* u);
+int dqmc_sweep_beta_to_0(dqmc_engine* e, const int32_t* perm, const uint8_t* kprop, const double* u);
+int dqmc_sync(dqmc_engine* e);
+int dqmc_get_stats(dqmc_engine* e, dqmc_stats* out);
+
+/* Fine-grained steps of the sweep, for parity tests and custom drivers.      */
+/* DQMC::propagate_GF_forward / _backward (source/dqmc.cpp:113-132,169-187).  */
+int dqmc_wrap_forward(dqmc_engine* e, int l);
+int dqmc_wrap_backward(dqmc_engine* e, int l);
+/* update::local_update for slice l (source/update.cpp:5-32); perm/kprop/u
+ * hold n_sites entries; *accepted receives the accepted count (synchronous). */
+int dqmc_local_update_slice(dqmc_engine* e, int l, const int32_t* perm,
+                            const uint8_t* kprop, const double* u, int* accepted);
+/* DQMC::calculate_Bbar (source/dqmc.cpp:88-105).                             */
+int dqmc_calculate_Bbar(dqmc_engine* e, int i_stack, double* Bbar);
+/* AttractiveHubbard::global_action (source/model.cpp:140-159).               */
+int dqmc_global_action(dqmc_engine* e, double* S);
+
+/* Number of accepted proposals / kernel time (ms, HIP events on the engine's
+ * stream) spent inside the local-update kernels since the last call -- the
+ * live measurement bench.py uses for the rank-1 roofline.                    */
+int dqmc_update_kernel_time(dqmc_engine* e, double* ms, int64_t* n_launches, int64_t* n_accepted);
+/* enable (1) / disable (0) the per-slice HIP-event timing above (default 0:
+ * events serialise nothing but cost a few microseconds per slice).           */
+int dqmc_set_profiling(dqmc_engine* e, int on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DQMC_HIP_H */

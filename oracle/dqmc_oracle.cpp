@@ -1,0 +1,552 @@
+/*
+ * dqmc_oracle.cpp -- CPU restatement of the kfkq/DQMC equal-time sweep.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py may load this library, and only as the checker
+ * or the timed CPU baseline; nothing under dqmc_amd/ links, imports or calls
+ * it.  The product path is the HIP library (dqmc_amd/csrc) and has no CPU
+ * fallback.
+ *
+ * PARITY UNPINNED: the reference ships no tests, golden
+ * vectors or fixtures, and cannot be compiled here (Armadillo is un-vendored
+ * and absent; CMakeLists.txt:13).  This restatement is therefore pinned only
+ * by (i) analytic known-answer cases (free fermions, tests/test_oracle.py),
+ * (ii) an independent numpy/scipy evaluation of the same algebra
+ * (oracle/numpy_ref.py; scipy's pivoted QR is LAPACK dgeqp3, the routine
+ * Armadillo forwards arma::qr(...,"vector") to), and (iii) agreement of its
+ * two interchangeable dense back ends: the built-in kernels below and the
+ * MKL/LAPACK routines the reference itself links (CMakeLists.txt:19-29),
+ * resolved with dlopen when present.
+ *
+ * Each function cites the reference file:line it follows (paths relative to
+ * /root/reference).  Third-party arithmetic the reference delegates to
+ * Armadillo (version unpinned) -> LAPACK is restated as: arma::qr "vector"
+ * = dgeqp3 + dorgqr; arma::solve = dgetrf/dgetrs (its rcond-triggered SVD
+ * fallback never fires on these well-conditioned systems); arma::log_det
+ * real part = sum log|u_ii| of dgetrf; expmat is not on the path (expK is an
+ * input).
+ *
+ * All matrices column-major fp64, leading dimension n.
+ */
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+#include <dlfcn.h>
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const std::string& msg) { g_err = msg; return code; }
+
+constexpr int OK = 0, EINVAL_ = -1, ENUMERIC_ = -3, ERANGE_ = -4;
+
+using vecd = std::vector<double>;
+
+/* ------------------------------------------------------------------ *
+ * LAPACK/BLAS back end (optional, dlopen): the routines the reference
+ * reaches through Armadillo.
+ * ------------------------------------------------------------------ */
+struct Lapack {
+    void* h = nullptr;
+    void (*dgemm)(const char*, const char*, const int*, const int*, const int*, const double*,
+                  const double*, const int*, const double*, const int*, const double*, double*, const int*) = nullptr;
+    void (*dgeqp3)(const int*, const int*, double*, const int*, int*, double*, double*, const int*, int*) = nullptr;
+    void (*dorgqr)(const int*, const int*, const int*, double*, const int*, const double*, double*, const int*, int*) = nullptr;
+    void (*dgetrf)(const int*, const int*, double*, const int*, int*, int*) = nullptr;
+    void (*dgetrs)(const char*, const int*, const int*, const double*, const int*, const int*, double*, const int*, int*) = nullptr;
+    void (*dger)(const int*, const int*, const double*, const double*, const int*, const double*, const int*, double*, const int*) = nullptr;
+    std::string name;
+    bool ok() const { return dgemm && dgeqp3 && dorgqr && dgetrf && dgetrs; }
+} g_lapack;
+bool g_use_lapack = false;
+std::string g_backend_name = "cpu-oracle:builtin";
+
+bool try_load_lapack() {
+    if (g_lapack.ok()) return true;
+    /* sequential threading, like the reference's libmkl_sequential
+     * (CMakeLists.txt:27) */
+    setenv("MKL_THREADING_LAYER", "SEQUENTIAL", 0);
+    setenv("OPENBLAS_NUM_THREADS", "1", 0);
+    const char* cands[] = {getenv("DQMC_ORACLE_LAPACK"), "libmkl_rt.so", "libmkl_rt.so.1", "/opt/conda/lib/libmkl_rt.so",
+                           "/opt/conda/lib/libmkl_rt.so.1", "liblapack.so.3", "libopenblas.so.0", nullptr};
+    for (int c = 0; c < 8; ++c) {
+        if (!cands[c]) { if (c == 0) continue; else break; }
+        void* h = dlopen(cands[c], RTLD_NOW | RTLD_GLOBAL);
+        if (!h) continue;
+        Lapack L; L.h = h; L.name = cands[c];
+        *(void**)&L.dgemm = dlsym(h, "dgemm_");
+        *(void**)&L.dgeqp3 = dlsym(h, "dgeqp3_");
+        *(void**)&L.dorgqr = dlsym(h, "dorgqr_");
+        *(void**)&L.dgetrf = dlsym(h, "dgetrf_");
+        *(void**)&L.dgetrs = dlsym(h, "dgetrs_");
+        *(void**)&L.dger = dlsym(h, "dger_");
+        if (L.ok()) { g_lapack = L; return true; }
+    }
+    return false;
+}
+
+/* ------------------------------------------------------------------ *
+ * built-in dense kernels
+ * ------------------------------------------------------------------ */
+
+/* C = op(A) * op(B), n x n.  Column-major; the j-k-i order makes the inner
+ * loop a unit-stride axpy the compiler vectorises; four columns of C are
+ * carried per pass so each A column is loaded once per four FMAs.           */
+void gemm_builtin(int n, const double* A, bool tA, const double* B, bool tB, double* C) {
+    vecd At, Bt;
+    if (tA) { At.resize((size_t)n * n); for (int j = 0; j < n; ++j) for (int i = 0; i < n; ++i) At[i + (size_t)n * j] = A[j + (size_t)n * i]; A = At.data(); }
+    if (tB) { Bt.resize((size_t)n * n); for (int j = 0; j < n; ++j) for (int i = 0; i < n; ++i) Bt[i + (size_t)n * j] = B[j + (size_t)n * i]; B = Bt.data(); }
+    std::fill(C, C + (size_t)n * n, 0.0);
+    int j = 0;
+    for (; j + 4 <= n; j += 4) {
+        double* c0 = C + (size_t)n * j; double* c1 = c0 + n; double* c2 = c1 + n; double* c3 = c2 + n;
+        for (int k = 0; k < n; ++k) {
+            const double* a = A + (size_t)n * k;
+            const double b0 = B[k + (size_t)n * j], b1 = B[k + (size_t)n * (j + 1)], b2 = B[k + (size_t)n * (j + 2)], b3 = B[k + (size_t)n * (j + 3)];
+            for (int i = 0; i < n; ++i) { const double av = a[i]; c0[i] += av * b0; c1[i] += av * b1; c2[i] += av * b2; c3[i] += av * b3; }
+        }
+    }
+    for (; j < n; ++j) {
+        double* c0 = C + (size_t)n * j;
+        for (int k = 0; k < n; ++k) { const double* a = A + (size_t)n * k; const double b0 = B[k + (size_t)n * j]; for (int i = 0; i < n; ++i) c0[i] += a[i] * b0; }
+    }
+}
+
+void gemm(int n, const double* A, bool tA, const double* B, bool tB, double* C) {
+    if (g_use_lapack) {
+        const double one = 1.0, zero = 0.0;
+        g_lapack.dgemm(tA ? "T" : "N", tB ? "T" : "N", &n, &n, &n, &one, A, &n, B, &n, &zero, C, &n);
+    } else gemm_builtin(n, A, tA, B, tB, C);
+}
+
+double nrm2(int m, const double* x) {            /* scaled 2-norm, as dnrm2 */
+    double scale = 0.0, ssq = 1.0;
+    for (int i = 0; i < m; ++i) if (x[i] != 0.0) {
+        const double a = std::fabs(x[i]);
+        if (scale < a) { ssq = 1.0 + ssq * (scale / a) * (scale / a); scale = a; } else ssq += (a / scale) * (a / scale);
+    }
+    return scale * std::sqrt(ssq);
+}
+
+/* Householder QR with column pivoting, LAPACK dgeqp3 semantics in its
+ * unblocked form (dlaqp2): pivot = remaining column of largest partial
+ * 2-norm, lowest index on ties; partial norms down-dated and recomputed on
+ * cancellation.  On exit A holds R0 above the diagonal and the reflector
+ * vectors below, jpvt (0-based) satisfies M(:, jpvt) = Q R0.               */
+int qrcp_builtin(int n, double* A, double* tau, int* jpvt) {
+    vecd vn1(n), vn2(n), w(n);
+    const double tol3z = std::sqrt(std::numeric_limits<double>::epsilon() * 0.5);
+    for (int j = 0; j < n; ++j) { jpvt[j] = j; vn1[j] = vn2[j] = nrm2(n, A + (size_t)n * j); }
+    for (int i = 0; i < n; ++i) {
+        int pvt = i; double best = vn1[i];
+        for (int j = i + 1; j < n; ++j) if (vn1[j] > best) { best = vn1[j]; pvt = j; }
+        if (pvt != i) {
+            double* a = A + (size_t)n * pvt; double* b = A + (size_t)n * i;
+            for (int r = 0; r < n; ++r) std::swap(a[r], b[r]);
+            std::swap(jpvt[pvt], jpvt[i]); vn1[pvt] = vn1[i]; vn2[pvt] = vn2[i];
+        }
+        double* v = A + (size_t)n * i + i; const int m = n - i;
+        /* dlarfg */
+        double alpha = v[0]; const double xnorm = m > 1 ? nrm2(m - 1, v + 1) : 0.0;
+        if (xnorm == 0.0) { tau[i] = 0.0; }
+        else {
+            double beta = -std::copysign(std::hypot(alpha, xnorm), alpha);
+            tau[i] = (beta - alpha) / beta;
+            const double s = 1.0 / (alpha - beta);
+            for (int r = 1; r < m; ++r) v[r] *= s;
+            v[0] = beta;
+        }
+        /* apply H = I - tau v v^T to A[i:, i+1:] */
+        if (i + 1 < n && tau[i] != 0.0) {
+            const double aii = v[0]; v[0] = 1.0;
+            for (int j = i + 1; j < n; ++j) {
+                double* c = A + (size_t)n * j + i; double s = 0.0;
+                for (int r = 0; r < m; ++r) s += v[r] * c[r];
+                s *= tau[i];
+                for (int r = 0; r < m; ++r) c[r] -= s * v[r];
+            }
+            v[0] = aii;
+        }
+        for (int j = i + 1; j < n; ++j) if (vn1[j] != 0.0) {
+            double temp = std::fabs(A[i + (size_t)n * j]) / vn1[j];
+            temp = std::max(0.0, 1.0 - temp * temp);
+            const double r = vn1[j] / vn2[j];
+            const double temp2 = temp * r * r;
+            if (temp2 <= tol3z) {
+                if (i + 1 < n) { vn1[j] = nrm2(n - i - 1, A + (size_t)n * j + i + 1); vn2[j] = vn1[j]; }
+                else { vn1[j] = 0.0; vn2[j] = 0.0; }
+            } else vn1[j] *= std::sqrt(temp);
+        }
+    }
+    return OK;
+}
+
+/* dorg2r: form the full n x n Q from the reflectors in A / tau.             */
+void orgqr_builtin(int n, const double* A, const double* tau, double* Q) {
+    std::fill(Q, Q + (size_t)n * n, 0.0);
+    for (int i = 0; i < n; ++i) Q[i + (size_t)n * i] = 1.0;
+    vecd v(n);
+    for (int i = n - 1; i >= 0; --i) {
+        if (tau[i] == 0.0) continue;
+        const int m = n - i; v[0] = 1.0;
+        for (int r = 1; r < m; ++r) v[r] = A[(size_t)n * i + i + r];
+        for (int j = i; j < n; ++j) {
+            double* c = Q + (size_t)n * j + i; double s = 0.0;
+            for (int r = 0; r < m; ++r) s += v[r] * c[r];
+            s *= tau[i];
+            for (int r = 0; r < m; ++r) c[r] -= s * v[r];
+        }
+    }
+}
+
+/* dgetf2-style LU with partial (row) pivoting, right-looking.               */
+int lu_builtin(int n, double* A, int* ipiv) {
+    for (int k = 0; k < n; ++k) {
+        int p = k; double best = std::fabs(A[k + (size_t)n * k]);
+        for (int r = k + 1; r < n; ++r) { const double a = std::fabs(A[r + (size_t)n * k]); if (a > best) { best = a; p = r; } }
+        ipiv[k] = p;
+        if (best == 0.0 || !(best == best)) return ENUMERIC_;
+        if (p != k) for (int j = 0; j < n; ++j) std::swap(A[k + (size_t)n * j], A[p + (size_t)n * j]);
+        const double inv = 1.0 / A[k + (size_t)n * k];
+        for (int r = k + 1; r < n; ++r) A[r + (size_t)n * k] *= inv;
+        for (int j = k + 1; j < n; ++j) {
+            const double akj = A[k + (size_t)n * j]; double* c = A + (size_t)n * j; const double* l = A + (size_t)n * k;
+            if (akj != 0.0) for (int r = k + 1; r < n; ++r) c[r] -= l[r] * akj;
+        }
+    }
+    return OK;
+}
+void lu_solve_builtin(int n, const double* LU, const int* ipiv, int nrhs, double* B) {
+    for (int j = 0; j < nrhs; ++j) {
+        double* b = B + (size_t)n * j;
+        for (int k = 0; k < n; ++k) if (ipiv[k] != k) std::swap(b[k], b[ipiv[k]]);
+        for (int k = 0; k < n; ++k) { const double bk = b[k]; if (bk != 0.0) { const double* l = LU + (size_t)n * k; for (int r = k + 1; r < n; ++r) b[r] -= l[r] * bk; } }
+        for (int k = n - 1; k >= 0; --k) { b[k] /= LU[k + (size_t)n * k]; const double bk = b[k]; const double* uu = LU + (size_t)n * k; for (int r = 0; r < k; ++r) b[r] -= uu[r] * bk; }
+    }
+}
+
+/* QRCP + full Q: arma::qr(Q,R,P,M,"vector") (source/stablelinalg.cpp:41).   */
+int qr_pivoted(int n, const double* M, double* Q, double* R0, int* P) {
+    vecd A(M, M + (size_t)n * n), tau(n);
+    if (g_use_lapack) {
+        std::vector<int> jp(n, 0); int info = 0, lwork = -1; double wq = 0;
+        g_lapack.dgeqp3(&n, &n, A.data(), &n, jp.data(), tau.data(), &wq, &lwork, &info);
+        lwork = std::max((int)wq, 3 * n + 1); vecd work(lwork);
+        g_lapack.dgeqp3(&n, &n, A.data(), &n, jp.data(), tau.data(), work.data(), &lwork, &info);
+        if (info != 0) return ENUMERIC_;
+        for (int j = 0; j < n; ++j) P[j] = jp[j] - 1;
+        for (int j = 0; j < n; ++j) for (int i = 0; i < n; ++i) R0[i + (size_t)n * j] = i <= j ? A[i + (size_t)n * j] : 0.0;
+        lwork = -1; g_lapack.dorgqr(&n, &n, &n, A.data(), &n, tau.data(), &wq, &lwork, &info);
+        lwork = std::max((int)wq, n); work.resize(lwork);
+        g_lapack.dorgqr(&n, &n, &n, A.data(), &n, tau.data(), work.data(), &lwork, &info);
+        if (info != 0) return ENUMERIC_;
+        std::copy(A.begin(), A.end(), Q);
+    } else {
+        int rc = qrcp_builtin(n, A.data(), tau.data(), P); if (rc) return rc;
+        for (int j = 0; j < n; ++j) for (int i = 0; i < n; ++i) R0[i + (size_t)n * j] = i <= j ? A[i + (size_t)n * j] : 0.0;
+        orgqr_builtin(n, A.data(), tau.data(), Q);
+    }
+    return OK;
+}
+
+int lu_factor(int n, double* A, int* ipiv) {
+    if (g_use_lapack) { int info = 0; g_lapack.dgetrf(&n, &n, A, &n, ipiv, &info); for (int i = 0; i < n; ++i) ipiv[i] -= 1; return info == 0 ? OK : ENUMERIC_; }
+    return lu_builtin(n, A, ipiv);
+}
+void lu_solve(int n, const double* LU, const int* ipiv, int nrhs, double* B) {
+    if (g_use_lapack) { std::vector<int> ip(n); for (int i = 0; i < n; ++i) ip[i] = ipiv[i] + 1; int info = 0; g_lapack.dgetrs("N", &n, &nrhs, LU, &n, ip.data(), B, &n, &info); }
+    else lu_solve_builtin(n, LU, ipiv, nrhs, B);
+}
+/* arma::solve(X, A, B) restated as dgesv (source/stablelinalg.cpp:112,123,147,155) */
+int solve(int n, const double* A, const double* B, double* X) {
+    vecd LU(A, A + (size_t)n * n); std::vector<int> ipiv(n);
+    int rc = lu_factor(n, LU.data(), ipiv.data()); if (rc) return rc;
+    std::copy(B, B + (size_t)n * n, X); lu_solve(n, LU.data(), ipiv.data(), n, X); return OK;
+}
+
+/* ------------------------------------------------------------------ *
+ * stablelinalg restatement
+ * ------------------------------------------------------------------ */
+struct LDR { int n = 0; vecd L, d, R; void alloc(int n_) { n = n_; L.assign((size_t)n * n, 0.0); d.assign(n, 0.0); R.assign((size_t)n * n, 0.0); } };
+
+/* source/stablelinalg.cpp:9-14 */
+void diag_mul_mat(int n, const double* dg, const double* M, double* out) { for (int j = 0; j < n; ++j) for (int i = 0; i < n; ++i) out[i + (size_t)n * j] = dg[i] * M[i + (size_t)n * j]; }
+/* source/stablelinalg.cpp:16-21 */
+void mat_mul_diag(int n, const double* M, const double* dg, double* out) { for (int j = 0; j < n; ++j) for (int i = 0; i < n; ++i) out[i + (size_t)n * j] = M[i + (size_t)n * j] * dg[j]; }
+
+/* stablelinalg::to_LDR, source/stablelinalg.cpp:35-55 */
+int to_ldr(int n, const double* M, LDR& F) {
+    F.alloc(n); vecd R0((size_t)n * n); std::vector<int> P(n);
+    int rc = qr_pivoted(n, M, F.L.data(), R0.data(), P.data()); if (rc) return rc;
+    vecd dinv(n);
+    for (int i = 0; i < n; ++i) { F.d[i] = std::fabs(R0[i + (size_t)n * i]); dinv[i] = 1.0 / F.d[i]; }     /* :47-48 */
+    vecd Rn((size_t)n * n); diag_mul_mat(n, dinv.data(), R0.data(), Rn.data());                            /* :49 */
+    /* :51-52  R_final = R_normalized.cols(sort_index(P)): column P[j] of the result is column j of Rn */
+    for (int j = 0; j < n; ++j) std::copy(Rn.begin() + (size_t)n * j, Rn.begin() + (size_t)n * (j + 1), F.R.begin() + (size_t)n * P[j]);
+    return OK;
+}
+/* stablelinalg::ldr_mul_mat, source/stablelinalg.cpp:57-67 */
+int ldr_mul_mat(const LDR& F, const double* M, LDR& out) {
+    const int n = F.n; vecd T((size_t)n * n), T2((size_t)n * n);
+    gemm(n, F.R.data(), false, M, false, T.data()); diag_mul_mat(n, F.d.data(), T.data(), T2.data());
+    LDR q; int rc = to_ldr(n, T2.data(), q); if (rc) return rc;
+    out.alloc(n); gemm(n, F.L.data(), false, q.L.data(), false, out.L.data()); out.d = q.d; out.R = q.R; return OK;
+}
+/* stablelinalg::mat_mul_ldr, source/stablelinalg.cpp:69-79 */
+int mat_mul_ldr(const double* M, const LDR& F, LDR& out) {
+    const int n = F.n; vecd T((size_t)n * n), T2((size_t)n * n);
+    gemm(n, M, false, F.L.data(), false, T.data()); mat_mul_diag(n, T.data(), F.d.data(), T2.data());
+    LDR q; int rc = to_ldr(n, T2.data(), q); if (rc) return rc;
+    out.alloc(n); out.L = q.L; out.d = q.d; gemm(n, q.R.data(), false, F.R.data(), false, out.R.data()); return OK;
+}
+/* stablelinalg::ldr_mul_ldr, source/stablelinalg.cpp:81-92 */
+int ldr_mul_ldr(const LDR& F1, const LDR& F2, LDR& out) {
+    const int n = F1.n; vecd T((size_t)n * n), T2((size_t)n * n);
+    gemm(n, F1.R.data(), false, F2.L.data(), false, T.data());
+    diag_mul_mat(n, F1.d.data(), T.data(), T2.data()); mat_mul_diag(n, T2.data(), F2.d.data(), T.data());
+    LDR q; int rc = to_ldr(n, T.data(), q); if (rc) return rc;
+    out.alloc(n); gemm(n, F1.L.data(), false, q.L.data(), false, out.L.data()); out.d = q.d;
+    gemm(n, q.R.data(), false, F2.R.data(), false, out.R.data()); return OK;
+}
+void split_d(const vecd& d, vecd& large, vecd& small) {          /* source/stablelinalg.cpp:100-108 */
+    const int n = (int)d.size(); large.assign(n, 1.0); small.assign(n, 1.0);
+    for (int i = 0; i < n; ++i) { if (d[i] >= 1.0) large[i] = d[i]; else small[i] = d[i]; }
+}
+/* stablelinalg::inv_I_plus_ldr, source/stablelinalg.cpp:94-126 */
+int inv_I_plus_ldr(const LDR& F, double* G, double* logdet) {
+    const int n = F.n; vecd Dl, Ds; split_d(F.d, Dl, Ds);
+    vecd Dinv((size_t)n * n, 0.0); for (int i = 0; i < n; ++i) Dinv[i + (size_t)n * i] = 1.0 / Dl[i];
+    vecd X((size_t)n * n); int rc = solve(n, F.R.data(), Dinv.data(), X.data()); if (rc) return rc;      /* :112 */
+    vecd M((size_t)n * n); mat_mul_diag(n, F.L.data(), Ds.data(), M.data());                               /* :114 */
+    for (size_t k = 0; k < (size_t)n * n; ++k) M[k] = X[k] + M[k];                                         /* :116 */
+    double ld = 0.0; for (int i = 0; i < n; ++i) ld += std::log(Dl[i]);                                    /* :118 */
+    { vecd LU(M); std::vector<int> ip(n); rc = lu_factor(n, LU.data(), ip.data()); if (rc) return rc;
+      double s = 0.0; for (int i = 0; i < n; ++i) s += std::log(std::fabs(LU[i + (size_t)n * i])); ld += s; }   /* :119-120 */
+    if (logdet) *logdet = ld;
+    /* :122-125  G^T = solve(M^T, X^T) */
+    vecd Mt((size_t)n * n), Xt((size_t)n * n), Gt((size_t)n * n);
+    for (int j = 0; j < n; ++j) for (int i = 0; i < n; ++i) { Mt[i + (size_t)n * j] = M[j + (size_t)n * i]; Xt[i + (size_t)n * j] = X[j + (size_t)n * i]; }
+    rc = solve(n, Mt.data(), Xt.data(), Gt.data()); if (rc) return rc;
+    for (int j = 0; j < n; ++j) for (int i = 0; i < n; ++i) G[i + (size_t)n * j] = Gt[j + (size_t)n * i];
+    return OK;
+}
+/* stablelinalg::inv_I_plus_ldr_mul_ldr, source/stablelinalg.cpp:128-158 */
+int inv_I_plus_ldr_mul_ldr(const LDR& F1, const LDR& F2, double* G) {
+    const int n = F1.n; vecd D1l, D1s, D2l, D2s; split_d(F1.d, D1l, D1s); split_d(F2.d, D2l, D2s);
+    vecd Dinv((size_t)n * n, 0.0); for (int i = 0; i < n; ++i) Dinv[i + (size_t)n * i] = 1.0 / D2l[i];
+    vecd X((size_t)n * n); int rc = solve(n, F2.R.data(), Dinv.data(), X.data()); if (rc) return rc;     /* :147 */
+    vecd d1linv(n); for (int i = 0; i < n; ++i) d1linv[i] = 1.0 / D1l[i];
+    vecd T((size_t)n * n), TA((size_t)n * n), T2((size_t)n * n), TB((size_t)n * n);
+    gemm(n, F1.L.data(), true, X.data(), false, T.data()); diag_mul_mat(n, d1linv.data(), T.data(), TA.data());   /* :149 */
+    mat_mul_diag(n, F2.L.data(), D2s.data(), T.data()); gemm(n, F1.R.data(), false, T.data(), false, T2.data());
+    diag_mul_mat(n, D1s.data(), T2.data(), TB.data());                                                     /* :150 */
+    vecd M((size_t)n * n); for (size_t k = 0; k < (size_t)n * n; ++k) M[k] = TA[k] + TB[k];                /* :151 */
+    vecd RHS((size_t)n * n);                                                                               /* :153 diag(1/D1l) L1^T */
+    for (int j = 0; j < n; ++j) for (int i = 0; i < n; ++i) RHS[i + (size_t)n * j] = d1linv[i] * F1.L[j + (size_t)n * i];
+    vecd Y((size_t)n * n); rc = solve(n, M.data(), RHS.data(), Y.data()); if (rc) return rc;             /* :155 */
+    gemm(n, X.data(), false, Y.data(), false, G);                                                         /* :157 */
+    return OK;
+}
+
+/* ------------------------------------------------------------------ *
+ * engine: DQMC + AttractiveHubbard + GHQField state of one chain
+ * ------------------------------------------------------------------ */
+struct Stats { double acc_rate = 0, max_err = 0, sum_err = 0, n_err = 0; int64_t n_accepted = 0, n_proposed = 0; };
+
+struct Engine {
+    int n = 0, nt = 0, n_stab = 0, n_stack = 0;
+    double g = 0, alpha = -1.0, gamma[4], eta[4];
+    std::vector<int> loc_l_end;
+    vecd expK, invexpK;
+    std::vector<int> fields;          /* [l*n + i] */
+    vecd G; double logdet = 0;
+    std::vector<LDR> stack;
+    Stats st;
+    static constexpr int proposal[4][3] = {{1, 2, 3}, {0, 2, 3}, {0, 1, 3}, {0, 1, 2}};   /* include/field.h:45-48 */
+
+    int stack_idx(int l) const { return l / n_stab; }     /* include/dqmc.h:47 */
+    int local_l(int l) const { return l % n_stab; }       /* include/dqmc.h:48 */
+
+    /* AttractiveHubbard::expV / invexpV, source/model.cpp:62-84 */
+    void expV(int l, vecd& v, double sign) const { v.resize(n); for (int i = 0; i < n; ++i) v[i] = std::exp(sign * g * eta[fields[(size_t)l * n + i]]); }
+    /* DQMC::calculate_B / calculate_invB, source/dqmc.cpp:78-86 */
+    void B(int l, vecd& out) const { vecd v; expV(l, v, 1.0); out.resize((size_t)n * n); diag_mul_mat(n, v.data(), expK.data(), out.data()); }
+    void invB(int l, vecd& out) const { vecd v; expV(l, v, -1.0); out.resize((size_t)n * n); mat_mul_diag(n, invexpK.data(), v.data(), out.data()); }
+    /* DQMC::calculate_Bbar, source/dqmc.cpp:88-105 (starts from I, :91) */
+    void Bbar(int i_stack, vecd& out) const {
+        out.assign((size_t)n * n, 0.0); for (int i = 0; i < n; ++i) out[i + (size_t)n * i] = 1.0;
+        vecd Bl, T((size_t)n * n);
+        for (int loc = 0; loc <= loc_l_end[i_stack]; ++loc) { B(i_stack * n_stab + loc, Bl); gemm(n, Bl.data(), false, out.data(), false, T.data()); out.swap(T); T.resize((size_t)n * n); }
+    }
+    /* DQMC::init_stacks, source/dqmc.cpp:43-59 */
+    int init_stacks() {
+        stack.assign(n_stack, LDR()); vecd bb;
+        for (int i = n_stack - 1; i >= 0; --i) {
+            Bbar(i, bb); LDR f; int rc = to_ldr(n, bb.data(), f); if (rc) return rc;
+            if (i == n_stack - 1) stack[i] = f; else { rc = ldr_mul_ldr(stack[i + 1], f, stack[i]); if (rc) return rc; }
+        }
+        return OK;
+    }
+    /* DQMC::init_greenfunctions, source/dqmc.cpp:61-72 */
+    int init_green() { G.resize((size_t)n * n); return inv_I_plus_ldr(stack[0], G.data(), &logdet); }
+    /* DQMC::propagate_GF_forward, source/dqmc.cpp:113-132: G = (B G) invB */
+    void wrap_forward(int l) { vecd b, ib, T((size_t)n * n); B(l, b); invB(l, ib); gemm(n, b.data(), false, G.data(), false, T.data()); gemm(n, T.data(), false, ib.data(), false, G.data()); }
+    /* DQMC::propagate_GF_backward, source/dqmc.cpp:169-187: G = (invB G) B */
+    void wrap_backward(int l) { vecd b, ib, T((size_t)n * n); B(l, b); invB(l, ib); gemm(n, ib.data(), false, G.data(), false, T.data()); gemm(n, T.data(), false, b.data(), false, G.data()); }
+    /* DQMC::check_error, source/dqmc.cpp:317-329 */
+    double check_error(const vecd& A, const vecd& Bm) {
+        double e = 0.0; for (size_t k = 0; k < A.size(); ++k) e = std::max(e, std::fabs(A[k] - Bm[k]));
+        if (e > st.max_err) st.max_err = e;
+        st.sum_err += e; st.n_err += 1.0; return e;
+    }
+    /* AttractiveHubbard::update_greens_local, source/model.cpp:124-138 */
+    void rank1(int i, double delta) {
+        const double pref = delta / (1.0 + (1.0 - G[i + (size_t)n * i]) * delta);
+        vecd U(G.begin() + (size_t)n * i, G.begin() + (size_t)n * (i + 1)), V(n);
+        for (int k = 0; k < n; ++k) V[k] = G[i + (size_t)n * k];
+        V[i] -= 1.0;
+        if (g_use_lapack && g_lapack.dger) { const int one = 1; g_lapack.dger(&n, &n, &pref, U.data(), &one, V.data(), &one, G.data(), &n); return; }
+        for (int k = 0; k < n; ++k) { const double s = pref * V[k]; double* c = G.data() + (size_t)n * k; for (int r = 0; r < n; ++r) c[r] += U[r] * s; }
+    }
+    /* update::local_update, source/update.cpp:5-32 with the random stream
+     * (perm, kprop, u) supplied by the caller; ratio per source/model.cpp:90-122 */
+    int local_update(int l, const int32_t* perm, const uint8_t* kprop, const double* u) {
+        int accepted = 0;
+        for (int idx = 0; idx < n; ++idx) {
+            const int i = perm[idx];
+            const int old_f = fields[(size_t)l * n + i];
+            const int new_f = proposal[old_f][kprop[idx]];
+            const double gammaR = gamma[new_f] / gamma[old_f];
+            const double d_eta = eta[new_f] - eta[old_f];
+            const double bosonR = std::exp(alpha * g * d_eta);
+            const double delta = (1.0 / bosonR) - 1.0;
+            const double detR_flv = 1.0 + (1.0 - G[i + (size_t)n * i]) * delta;
+            const double R = gammaR * bosonR * std::pow(detR_flv, 2);
+            const double p = std::min(1.0, std::fabs(R));
+            if (u[idx] < p) { accepted += 1; rank1(i, delta); fields[(size_t)l * n + i] = new_f; }
+        }
+        st.n_accepted += accepted; st.n_proposed += n;
+        st.acc_rate += (static_cast<double>(accepted) / n) / nt;          /* source/dqmc.cpp:366,424 */
+        return accepted;
+    }
+    /* DQMC::sweep_0_to_beta, source/dqmc.cpp:337-396 */
+    int sweep_fwd(const int32_t* perm, const uint8_t* kprop, const double* u) {
+        for (int l = 0; l < nt; ++l) {
+            wrap_forward(l);
+            local_update(l, perm + (size_t)l * n, kprop + (size_t)l * n, u + (size_t)l * n);
+            const int is = stack_idx(l);
+            if (local_l(l) == loc_l_end[is]) {
+                vecd Gtmp = G, bb; Bbar(is, bb); int rc;
+                /* update_stack_forward :134-146 */
+                if (is == 0) rc = to_ldr(n, bb.data(), stack[0]); else { LDR o; rc = mat_mul_ldr(bb.data(), stack[is - 1], o); stack[is] = o; }
+                if (rc) return rc;
+                /* stabilize_GF_forward :148-161 */
+                if (l == nt - 1) rc = inv_I_plus_ldr(stack[is], G.data(), &logdet); else rc = inv_I_plus_ldr_mul_ldr(stack[is], stack[is + 1], G.data());
+                if (rc) return rc;
+                check_error(Gtmp, G);
+            }
+        }
+        return OK;
+    }
+    /* DQMC::sweep_beta_to_0, source/dqmc.cpp:398-456 */
+    int sweep_bwd(const int32_t* perm, const uint8_t* kprop, const double* u) {
+        for (int l = nt - 1; l >= 0; --l) {
+            local_update(l, perm + (size_t)l * n, kprop + (size_t)l * n, u + (size_t)l * n);
+            wrap_backward(l);
+            const int is = stack_idx(l);
+            if (local_l(l) == 0) {
+                vecd Gtmp = G, bb; Bbar(is, bb); int rc;
+                /* update_stack_backward :189-201 */
+                if (is == n_stack - 1) rc = to_ldr(n, bb.data(), stack[is]); else { LDR o; rc = ldr_mul_mat(stack[is + 1], bb.data(), o); stack[is] = o; }
+                if (rc) return rc;
+                /* stabilize_GF_backward :203-215 */
+                if (l == 0) rc = inv_I_plus_ldr(stack[is], G.data(), &logdet); else rc = inv_I_plus_ldr_mul_ldr(stack[is - 1], stack[is], G.data());
+                if (rc) return rc;
+                check_error(Gtmp, G);
+            }
+        }
+        return OK;
+    }
+    /* AttractiveHubbard::global_action, source/model.cpp:140-159 (sums over
+     * arma::imat memory order: column-major nt x nv, i.e. i outer, l inner) */
+    double global_action() const {
+        double S = -2.0 * logdet, lb = 0.0, lg = 0.0;
+        for (int i = 0; i < n; ++i) for (int l = 0; l < nt; ++l) { const int f = fields[(size_t)l * n + i]; lb += alpha * g * eta[f]; lg += std::log(gamma[f]); }
+        S -= lb + lg; return S;
+    }
+};
+constexpr int Engine::proposal[4][3];
+
+void load_ldr(int n, const double* L, const double* d, const double* R, LDR& F) { F.alloc(n); std::copy(L, L + (size_t)n * n, F.L.begin()); std::copy(d, d + n, F.d.begin()); std::copy(R, R + (size_t)n * n, F.R.begin()); }
+void store_ldr(const LDR& F, double* L, double* d, double* R) { std::copy(F.L.begin(), F.L.end(), L); std::copy(F.d.begin(), F.d.end(), d); std::copy(F.R.begin(), F.R.end(), R); }
+
+}  // namespace
+
+/* ====================================================================== *
+ * C ABI: same function set as include/dqmc_hip.h with prefix orc_
+ * ====================================================================== */
+extern "C" {
+
+struct orc_stats { double acc_rate, max_err, sum_err, n_err; int64_t n_accepted, n_proposed; };
+typedef struct Engine orc_engine;
+
+const char* orc_last_error(void) { return g_err.c_str(); }
+const char* orc_backend(void) { return g_backend_name.c_str(); }
+int orc_device_count(void) { return 0; }
+
+/* "builtin" or "lapack"; returns 0 on success, -1 if LAPACK cannot be loaded */
+int orc_set_backend(const char* name) {
+    if (!name) return EINVAL_;
+    if (!strcmp(name, "builtin")) { g_use_lapack = false; g_backend_name = "cpu-oracle:builtin"; return OK; }
+    if (!strcmp(name, "lapack")) { if (!try_load_lapack()) return fail(EINVAL_, "no LAPACK library could be loaded"); g_use_lapack = true; g_backend_name = "cpu-oracle:lapack(" + g_lapack.name + ")"; return OK; }
+    return fail(EINVAL_, "unknown backend");
+}
+
+int orc_to_ldr(int n, const double* M, double* L, double* d, double* R) { LDR F; int rc = to_ldr(n, M, F); if (rc) return fail(rc, "QR decomposition failed in to_LDR"); store_ldr(F, L, d, R); return OK; }
+int orc_ldr_mul_mat(int n, const double* L, const double* d, const double* R, const double* M, double* Lo, double* d_o, double* Ro) { LDR F, O; load_ldr(n, L, d, R, F); int rc = ldr_mul_mat(F, M, O); if (rc) return fail(rc, "ldr_mul_mat failed"); store_ldr(O, Lo, d_o, Ro); return OK; }
+int orc_mat_mul_ldr(int n, const double* M, const double* L, const double* d, const double* R, double* Lo, double* d_o, double* Ro) { LDR F, O; load_ldr(n, L, d, R, F); int rc = mat_mul_ldr(M, F, O); if (rc) return fail(rc, "mat_mul_ldr failed"); store_ldr(O, Lo, d_o, Ro); return OK; }
+int orc_ldr_mul_ldr(int n, const double* L1, const double* d1, const double* R1, const double* L2, const double* d2, const double* R2, double* Lo, double* d_o, double* Ro) { LDR A, B, O; load_ldr(n, L1, d1, R1, A); load_ldr(n, L2, d2, R2, B); int rc = ldr_mul_ldr(A, B, O); if (rc) return fail(rc, "ldr_mul_ldr failed"); store_ldr(O, Lo, d_o, Ro); return OK; }
+int orc_inv_I_plus_ldr(int n, const double* L, const double* d, const double* R, double* G, double* logdet) { LDR F; load_ldr(n, L, d, R, F); int rc = inv_I_plus_ldr(F, G, logdet); return rc ? fail(rc, "inv_I_plus_ldr failed") : OK; }
+int orc_inv_I_plus_ldr_mul_ldr(int n, const double* L1, const double* d1, const double* R1, const double* L2, const double* d2, const double* R2, double* G) { LDR A, B; load_ldr(n, L1, d1, R1, A); load_ldr(n, L2, d2, R2, B); int rc = inv_I_plus_ldr_mul_ldr(A, B, G); return rc ? fail(rc, "inv_I_plus_ldr_mul_ldr failed") : OK; }
+int orc_gemm(int n, const double* A, int tA, const double* B, int tB, double* C) { gemm(n, A, tA != 0, B, tB != 0, C); return OK; }
+int orc_rank1_update(int n, double* G, int i, double delta) { if (i < 0 || i >= n) return fail(ERANGE_, "site index"); Engine e; e.n = n; e.G.assign(G, G + (size_t)n * n); e.rank1(i, delta); std::copy(e.G.begin(), e.G.end(), G); return OK; }
+
+int orc_create(orc_engine** out, int /*device*/, int n_sites, int nt, int n_stab, double g, const double gamma[4], const double eta[4], const double* expK, const double* invexpK) {
+    if (!out || n_sites <= 0 || nt <= 0 || n_stab <= 0 || !expK || !invexpK) return fail(EINVAL_, "bad argument");
+    Engine* e = new Engine; e->n = n_sites; e->nt = nt; e->n_stab = n_stab; e->g = g;
+    e->n_stack = (int)std::ceil(static_cast<double>(nt) / n_stab);                  /* source/dqmc.cpp:10 */
+    e->loc_l_end.resize(e->n_stack);
+    for (int i = 0; i < e->n_stack; ++i) { e->loc_l_end[i] = n_stab - 1; if (i == e->n_stack - 1 && nt % n_stab != 0) e->loc_l_end[i] = nt % n_stab - 1; }   /* :13-18 */
+    for (int k = 0; k < 4; ++k) { e->gamma[k] = gamma[k]; e->eta[k] = eta[k]; }
+    e->expK.assign(expK, expK + (size_t)n_sites * n_sites); e->invexpK.assign(invexpK, invexpK + (size_t)n_sites * n_sites);
+    e->fields.assign((size_t)nt * n_sites, 0); e->G.assign((size_t)n_sites * n_sites, 0.0); e->stack.assign(e->n_stack, LDR());
+    *out = e; return OK;
+}
+void orc_destroy(orc_engine* e) { delete e; }
+int orc_set_fields(orc_engine* e, const int64_t* f) { for (int i = 0; i < e->n; ++i) for (int l = 0; l < e->nt; ++l) { const int64_t v = f[l + (size_t)e->nt * i]; if (v < 0 || v > 3) return fail(EINVAL_, "field value outside {0,1,2,3}"); e->fields[(size_t)l * e->n + i] = (int)v; } return OK; }
+int orc_get_fields(orc_engine* e, int64_t* f) { for (int i = 0; i < e->n; ++i) for (int l = 0; l < e->nt; ++l) f[l + (size_t)e->nt * i] = e->fields[(size_t)l * e->n + i]; return OK; }
+int orc_init(orc_engine* e) { int rc = e->init_stacks(); if (rc) return fail(rc, "init_stacks failed"); rc = e->init_green(); return rc ? fail(rc, "init_greenfunctions failed") : OK; }
+int orc_get_G(orc_engine* e, double* G) { std::copy(e->G.begin(), e->G.end(), G); return OK; }
+int orc_set_G(orc_engine* e, const double* G) { e->G.assign(G, G + (size_t)e->n * e->n); return OK; }
+int orc_get_logdet(orc_engine* e, double* ld) { *ld = e->logdet; return OK; }
+int orc_n_stack(orc_engine* e) { return e->n_stack; }
+int orc_get_stack(orc_engine* e, int i, double* L, double* d, double* R) { if (i < 0 || i >= e->n_stack) return fail(ERANGE_, "LDR Stack index out of bounds"); if (e->stack[i].n == 0) return fail(EINVAL_, "stack not initialised"); store_ldr(e->stack[i], L, d, R); return OK; }
+int orc_sweep_0_to_beta(orc_engine* e, const int32_t* perm, const uint8_t* kprop, const double* u) { int rc = e->sweep_fwd(perm, kprop, u); return rc ? fail(rc, "sweep_0_to_beta failed") : OK; }
+int orc_sweep_beta_to_0(orc_engine* e, const int32_t* perm, const uint8_t* kprop, const double* u) { int rc = e->sweep_bwd(perm, kprop, u); return rc ? fail(rc, "sweep_beta_to_0 failed") : OK; }
+int orc_sync(orc_engine*) { return OK; }
+int orc_get_stats(orc_engine* e, orc_stats* o) { o->acc_rate = e->st.acc_rate; o->max_err = e->st.max_err; o->sum_err = e->st.sum_err; o->n_err = e->st.n_err; o->n_accepted = e->st.n_accepted; o->n_proposed = e->st.n_proposed; return OK; }
+int orc_wrap_forward(orc_engine* e, int l) { if (l < 0 || l >= e->nt) return fail(ERANGE_, "slice"); e->wrap_forward(l); return OK; }
+int orc_wrap_backward(orc_engine* e, int l) { if (l < 0 || l >= e->nt) return fail(ERANGE_, "slice"); e->wrap_backward(l); return OK; }
+int orc_local_update_slice(orc_engine* e, int l, const int32_t* perm, const uint8_t* kprop, const double* u, int* accepted) { if (l < 0 || l >= e->nt) return fail(ERANGE_, "slice"); int a = e->local_update(l, perm, kprop, u); if (accepted) *accepted = a; return OK; }
+int orc_calculate_Bbar(orc_engine* e, int is, double* out) { if (is < 0 || is >= e->n_stack) return fail(ERANGE_, "stack index"); vecd bb; e->Bbar(is, bb); std::copy(bb.begin(), bb.end(), out); return OK; }
+int orc_global_action(orc_engine* e, double* S) { *S = e->global_action(); return OK; }
+int orc_update_kernel_time(orc_engine*, double* ms, int64_t* nl, int64_t* na) { if (ms) *ms = 0; if (nl) *nl = 0; if (na) *na = 0; return OK; }
+int orc_set_profiling(orc_engine*, int) { return OK; }
+
+}  // extern "C"
