@@ -1,0 +1,27 @@
+# Builds the product library (HIP, gfx950), the host helper library and the CPU oracle.
+HIPCC ?= /opt/rocm/bin/hipcc
+ARCH  ?= gfx950
+CXX   ?= g++
+HIPFLAGS ?= -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-function
+CSRC := dqmc_amd/csrc
+OBJS := $(CSRC)/gemm.o $(CSRC)/elementwise.o $(CSRC)/update.o $(CSRC)/qr.o $(CSRC)/lu.o $(CSRC)/engine.o
+
+all: dqmc_amd/libdqmc_hip.so dqmc_amd/libdqmc_host.so oracle
+
+$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/common.h include/dqmc_hip.h
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+dqmc_amd/libdqmc_hip.so: $(OBJS)
+	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ $(OBJS)
+
+dqmc_amd/libdqmc_host.so: dqmc_amd/host/host_capi.cpp dqmc_amd/host/dqmc_host.hpp include/dqmc_hip.h
+	$(CXX) -O2 -std=c++17 -fPIC -shared -Iinclude -Idqmc_amd/host -o $@ dqmc_amd/host/host_capi.cpp -ldl
+
+oracle:
+	$(MAKE) -C oracle
+
+clean:
+	rm -f $(CSRC)/*.o dqmc_amd/*.so
+	$(MAKE) -C oracle clean
+
+.PHONY: all oracle clean

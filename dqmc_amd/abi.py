@@ -43,7 +43,7 @@ ABI_SYMBOLS = [
     "last_error", "backend", "device_count",
     "to_ldr", "ldr_mul_mat", "mat_mul_ldr", "ldr_mul_ldr", "inv_I_plus_ldr", "inv_I_plus_ldr_mul_ldr",
     "gemm", "rank1_update",
-    "create", "destroy", "set_fields", "get_fields", "init", "get_G", "set_G", "get_logdet",
+    "create", "create_batch", "n_chains", "destroy", "set_fields", "get_fields", "init", "get_G", "set_G", "get_logdet",
     "n_stack", "get_stack", "sweep_0_to_beta", "sweep_beta_to_0", "sync", "get_stats",
     "wrap_forward", "wrap_backward", "local_update_slice", "calculate_Bbar", "global_action",
     "update_kernel_time", "set_profiling",
@@ -79,15 +79,19 @@ class DqmcLib:
             g(name).argtypes = [C.c_void_p]
         g("create").argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
                                 c_double_p, c_double_p, c_double_p, c_double_p]
+        if self.has_symbol("create_batch"):
+            g("create_batch").argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_double_p,
+                                          c_double_p, c_double_p, c_double_p, c_double_p]
+            g("n_chains").argtypes = [C.c_void_p]
         for name in ("get_G", "set_G", "get_logdet", "global_action"):
             g(name).argtypes = [C.c_void_p, c_double_p]
         g("get_stack").argtypes = [C.c_void_p, C.c_int, c_double_p, c_double_p, c_double_p]
         for name in ("sweep_0_to_beta", "sweep_beta_to_0"):
             g(name).argtypes = [C.c_void_p, c_int32_p, c_uint8_p, c_double_p]
-        g("get_stats").argtypes = [C.c_void_p, C.POINTER(Stats)]
+        g("get_stats").argtypes = [C.c_void_p, C.c_void_p]
         for name in ("wrap_forward", "wrap_backward"):
             g(name).argtypes = [C.c_void_p, C.c_int]
-        g("local_update_slice").argtypes = [C.c_void_p, C.c_int, c_int32_p, c_uint8_p, c_double_p, C.POINTER(C.c_int)]
+        g("local_update_slice").argtypes = [C.c_void_p, C.c_int, c_int32_p, c_uint8_p, c_double_p, C.c_void_p]
         g("calculate_Bbar").argtypes = [C.c_void_p, C.c_int, c_double_p]
         g("update_kernel_time").argtypes = [C.c_void_p, c_double_p, c_int64_p, c_int64_p]
         g("set_profiling").argtypes = [C.c_void_p, C.c_int]
@@ -170,19 +174,45 @@ class DqmcLib:
 
 
 class Engine:
-    """Handle onto one dqmc_engine (one Markov chain): class DQMC of the
-    reference (include/dqmc.h:21-93) with the model/field state it reads."""
+    """Handle onto one dqmc_engine: class DQMC of the reference
+    (include/dqmc.h:21-93) with the model/field state it reads.
 
-    def __init__(self, lib: DqmcLib, n_sites: int, nt: int, n_stab: int, g: float, gamma, eta,
-                 expK, invexpK, device: int = 0):
+    n_chains = None -> the single-chain ABI (dqmc_create); arrays have the
+    reference's shapes.  n_chains = C -> dqmc_create_batch; every per-chain
+    array gains a leading C dimension (g / expK / invexpK may be given once and
+    are then replicated)."""
+
+    def __init__(self, lib: DqmcLib, n_sites: int, nt: int, n_stab: int, g, gamma, eta,
+                 expK, invexpK, device: int = 0, n_chains: Optional[int] = None):
         self.lib, self.n, self.nt, self.n_stab = lib, int(n_sites), int(nt), int(n_stab)
+        self.batched = n_chains is not None
+        self.C = int(n_chains) if self.batched else 1
         gamma = np.ascontiguousarray(gamma, dtype=np.float64); eta = np.ascontiguousarray(eta, dtype=np.float64)
-        eK, iK = _f64(expK), _f64(invexpK)
-        assert eK.shape == (self.n, self.n) and iK.shape == (self.n, self.n)
         h = C.c_void_p()
-        lib.check(lib._sym("create")(C.byref(h), device, self.n, self.nt, self.n_stab, float(g),
-                                     _p(gamma), _p(eta), _p(eK), _p(iK)))
+        if not self.batched:
+            eK, iK = _f64(expK), _f64(invexpK)
+            assert eK.shape == (self.n, self.n) and iK.shape == (self.n, self.n)
+            lib.check(lib._sym("create")(C.byref(h), device, self.n, self.nt, self.n_stab, float(g),
+                                         _p(gamma), _p(eta), _p(eK), _p(iK)))
+        else:
+            gv = np.ascontiguousarray(np.broadcast_to(np.asarray(g, dtype=np.float64), (self.C,)))
+            eK = self._mats_in(np.broadcast_to(np.asarray(expK), (self.C, self.n, self.n)) if np.ndim(expK) == 2 else expK)
+            iK = self._mats_in(np.broadcast_to(np.asarray(invexpK), (self.C, self.n, self.n)) if np.ndim(invexpK) == 2 else invexpK)
+            lib.check(lib._sym("create_batch")(C.byref(h), device, self.C, self.n, self.nt, self.n_stab, _p(gv),
+                                               _p(gamma), _p(eta), _p(eK), _p(iK)))
         self._h: Optional[C.c_void_p] = h
+
+    # (C, n, n) python-indexed [c, i, j]  <->  C consecutive column-major matrices
+    def _mats_in(self, a) -> np.ndarray:
+        a = np.asarray(a, dtype=np.float64).reshape(self.C, self.n, self.n)
+        return np.ascontiguousarray(a.transpose(0, 2, 1))
+
+    def _mats_out(self, buf: np.ndarray) -> np.ndarray:
+        m = buf.reshape(self.C, self.n, self.n).transpose(0, 2, 1)
+        return m if self.batched else np.asfortranarray(m[0])
+
+    def _vec_out(self, buf: np.ndarray) -> np.ndarray:
+        return buf.reshape(self.C, -1) if self.batched else buf.reshape(-1)
 
     def close(self):
         if self._h is not None:
@@ -205,38 +235,41 @@ class Engine:
 
     # fields cross the ABI as arma::imat memory: nt x nv column-major int64
     def set_fields(self, fields):
-        """fields: integer array of shape (nt, n_sites), values in {0,1,2,3}."""
-        f = np.asfortranarray(np.asarray(fields).reshape(self.nt, self.n), dtype=np.int64)
+        """fields: integers in {0,1,2,3}, shape (nt, n_sites) [(C, nt, n_sites) when batched]."""
+        f = np.asarray(fields).reshape(self.C, self.nt, self.n)
+        f = np.ascontiguousarray(f.transpose(0, 2, 1), dtype=np.int64)     # [c][i][l] == column-major nt x nv
         self._c("set_fields", f.ctypes.data_as(c_int64_p))
 
     def get_fields(self) -> np.ndarray:
-        f = np.empty((self.nt, self.n), dtype=np.int64, order="F")
-        self._c("get_fields", f.ctypes.data_as(c_int64_p)); return f
+        f = np.empty((self.C, self.n, self.nt), dtype=np.int64)
+        self._c("get_fields", f.ctypes.data_as(c_int64_p))
+        f = f.transpose(0, 2, 1)
+        return f if self.batched else f[0]
 
     def init(self):
         self._c("init")
 
     def get_G(self) -> np.ndarray:
-        G = np.empty((self.n, self.n), order="F"); self._c("get_G", _p(G)); return G
+        G = np.empty(self.C * self.n * self.n); self._c("get_G", _p(G)); return self._mats_out(G)
 
     def set_G(self, G):
-        G = _f64(G); self._c("set_G", _p(G))
+        G = self._mats_in(G); self._c("set_G", _p(G))
 
-    def get_logdet(self) -> float:
-        v = C.c_double(0.0); self._c("get_logdet", C.cast(C.byref(v), c_double_p)); return v.value
+    def get_logdet(self):
+        v = np.zeros(self.C); self._c("get_logdet", _p(v)); return v if self.batched else float(v[0])
 
     def n_stack(self) -> int:
         return int(self.lib._sym("n_stack")(self._h))
 
     def get_stack(self, i: int):
-        n = self.n
-        L, d, R = np.empty((n, n), order="F"), np.empty(n), np.empty((n, n), order="F")
-        self._c("get_stack", int(i), _p(L), _p(d), _p(R)); return L, d, R
+        L, d, R = np.empty(self.C * self.n * self.n), np.empty(self.C * self.n), np.empty(self.C * self.n * self.n)
+        self._c("get_stack", int(i), _p(L), _p(d), _p(R))
+        return self._mats_out(L), self._vec_out(d), self._mats_out(R)
 
     def _stream(self, perm, kprop, u, rows):
-        perm = np.ascontiguousarray(np.asarray(perm).reshape(rows, self.n), dtype=np.int32)
-        kprop = np.ascontiguousarray(np.asarray(kprop).reshape(rows, self.n), dtype=np.uint8)
-        u = np.ascontiguousarray(np.asarray(u).reshape(rows, self.n), dtype=np.float64)
+        perm = np.ascontiguousarray(np.asarray(perm).reshape(self.C, rows, self.n), dtype=np.int32)
+        kprop = np.ascontiguousarray(np.asarray(kprop).reshape(self.C, rows, self.n), dtype=np.uint8)
+        u = np.ascontiguousarray(np.asarray(u).reshape(self.C, rows, self.n), dtype=np.float64)
         return perm, kprop, u
 
     def sweep_0_to_beta(self, perm, kprop, u):
@@ -250,8 +283,9 @@ class Engine:
     def sync(self):
         self._c("sync")
 
-    def stats(self) -> Stats:
-        s = Stats(); self._c("get_stats", C.byref(s)); return s
+    def stats(self):
+        arr = (Stats * self.C)(); self._c("get_stats", arr)
+        return list(arr) if self.batched else arr[0]
 
     def wrap_forward(self, l: int):
         self._c("wrap_forward", int(l))
@@ -259,17 +293,17 @@ class Engine:
     def wrap_backward(self, l: int):
         self._c("wrap_backward", int(l))
 
-    def local_update_slice(self, l: int, perm, kprop, u) -> int:
+    def local_update_slice(self, l: int, perm, kprop, u):
         perm, kprop, u = self._stream(perm, kprop, u, 1)
-        acc = C.c_int(0)
-        self._c("local_update_slice", int(l), perm.ctypes.data_as(c_int32_p), kprop.ctypes.data_as(c_uint8_p), _p(u), C.byref(acc))
-        return acc.value
+        acc = (C.c_int * self.C)()
+        self._c("local_update_slice", int(l), perm.ctypes.data_as(c_int32_p), kprop.ctypes.data_as(c_uint8_p), _p(u), acc)
+        return list(acc) if self.batched else acc[0]
 
     def calculate_Bbar(self, i_stack: int) -> np.ndarray:
-        B = np.empty((self.n, self.n), order="F"); self._c("calculate_Bbar", int(i_stack), _p(B)); return B
+        B = np.empty(self.C * self.n * self.n); self._c("calculate_Bbar", int(i_stack), _p(B)); return self._mats_out(B)
 
-    def global_action(self) -> float:
-        v = C.c_double(0.0); self._c("global_action", C.cast(C.byref(v), c_double_p)); return v.value
+    def global_action(self):
+        v = np.zeros(self.C); self._c("global_action", _p(v)); return v if self.batched else float(v[0])
 
     def set_profiling(self, on: bool):
         self._c("set_profiling", int(bool(on)))

@@ -1,0 +1,133 @@
+// common.h -- shared declarations of the gfx950 DQMC sweep library.
+//
+// Everything here is device-side plumbing for the kernels in this directory:
+// batched launch descriptors (every kernel takes a leading "chain" dimension
+// in blockIdx.y so one launch advances all Markov chains an engine owns),
+// error handling, and the launcher prototypes the engine (engine.hip) calls.
+// gfx950 only: wave = 64 lanes, fp64 MFMA 16x16x4.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <string>
+
+namespace dq {
+
+constexpr int WAVE = 64;
+
+// ---- error handling -------------------------------------------------------
+void set_error(const std::string& msg);          // thread-local last error
+const char* get_error();
+
+#define DQ_HIP(call)                                                                    \
+    do {                                                                                \
+        hipError_t _e = (call);                                                         \
+        if (_e != hipSuccess) {                                                         \
+            ::dq::set_error(std::string(#call) + ": " + hipGetErrorString(_e));         \
+            return -2; /* DQMC_ENODEVICE */                                             \
+        }                                                                               \
+    } while (0)
+
+// A batched column-major matrix: chain c lives at p + c*stride (stride 0 =
+// one matrix shared by all chains, e.g. expK when every chain has the same
+// beta).  Leading dimension is always n.
+struct Mat {
+    double* p = nullptr;
+    long stride = 0;
+    __host__ __device__ double* at(int c) const { return p + (long)c * stride; }
+};
+struct CMat {
+    const double* p = nullptr;
+    long stride = 0;
+    CMat() = default;
+    __host__ __device__ CMat(const double* p_, long s) : p(p_), stride(s) {}
+    __host__ __device__ CMat(const Mat& m) : p(m.p), stride(m.stride) {}
+    __host__ __device__ const double* at(int c) const { return p + (long)c * stride; }
+};
+using Vec = Mat;     // batched n-vectors use the same (pointer, stride) pair
+using CVec = CMat;
+
+// ---- gemm.hip ---------------------------------------------------------------
+// C[c] = diag(rs) * ( op(A[c]) * diag(ks) * B[c] ) * diag(cs)  (+ C[c] if accumulate)
+// rs/ks/cs may be null (= identity).  op(A) = A or A^T.  n x n x n, fp64 MFMA.
+struct GemmDesc {
+    CMat A, B;
+    Mat C;
+    CVec rs, ks, cs;
+    int n = 0;
+    int transA = 0;
+    int accumulate = 0;
+};
+int launch_gemm(const GemmDesc& g, int n_chains, hipStream_t s);
+
+// ---- elementwise.hip ----------------------------------------------------------
+// expV[l][i] = tabV[f[l][i]], invexpV likewise (AttractiveHubbard::expV/invexpV)
+int launch_build_expv(const int8_t* fields, long f_stride, int nt, int n, const double* tab_expv /*[chains][8]*/,
+                      double* expv, double* invexpv, long v_stride, int n_chains, hipStream_t s);
+// split d into 1/max(d,1) and min(d,1) (source/stablelinalg.cpp:100-108); also log-sum of max(d,1) into *logsum
+int launch_split_d(CVec d, Vec dl_inv, Vec ds, double* logsum, int n, int n_chains, hipStream_t s);
+// out = in (n*n)
+int launch_copy(CMat in, Mat out, long count, int n_chains, hipStream_t s);
+// out = I
+int launch_set_identity(Mat out, int n, int n_chains, hipStream_t s);
+// out[i,j] = rs[i]*in^T[i,j]  (= rs[i]*in[j,i]);  rs may be null
+int launch_transpose_scale(CMat in, Mat out, CVec rs, int n, int n_chains, hipStream_t s);
+// err[c] = max|A-B|
+int launch_max_abs_diff(CMat A, CMat B, double* err, long err_stride, int n, int n_chains, hipStream_t s);
+// C = A + B * diag(cs)   (cs may be null)
+int launch_add_scaled_cols(CMat A, CMat B, CVec cs, Mat C, int n, int n_chains, hipStream_t s);
+// out = diag(rs) * in
+int launch_scale_rows(CMat in, CVec rs, Mat out, int n, int n_chains, hipStream_t s);
+// fold one half-sweep's per-slice accepted counts and per-stabilisation errors into the per-chain stats
+struct DevStats { double acc_rate, max_err, sum_err, n_err; long long n_accepted, n_proposed; };
+int launch_fold_stats(DevStats* st, const int* acc, long acc_stride, int n_slices, const double* err, long err_stride, int n_err,
+                      int n, int nt, int n_chains, hipStream_t s);
+
+// ---- qr.hip -----------------------------------------------------------------
+// to_LDR on device: A (overwritten with reflectors / R0), outputs L (=Q), d, R.
+// work: per chain scratch of at least 4*n doubles + n ints (tau, norms, perm).
+struct QrWork {
+    double* tau; long tau_stride;      // n per chain
+    int* jpvt; long jpvt_stride;       // n per chain
+};
+int launch_to_ldr(Mat A, Mat L, Vec d, Mat R, QrWork w, int n, int n_chains, hipStream_t s);
+
+// ---- lu.hip -----------------------------------------------------------------
+// In-place LU with partial pivoting of A[c] (P A = L U); perm (n ints per
+// chain): row r of P*A is row perm[r] of A.  logabsdet[c] (+)= sum log|u_ii|
+// when non-null.  *info |= 1 on a zero / NaN pivot.
+int launch_lu(Mat A, int* perm, long perm_stride, double* logabsdet, int accumulate_logdet, int* info, int n, int n_chains, hipStream_t s);
+// Solve A X = B with the factors above, n right-hand sides.
+//   mode 0: X holds B on entry, overwritten by the solution.
+//   mode 1: B = diag(dg); X is overwritten.
+int launch_lu_solve(CMat LU, const int* perm, long perm_stride, Mat X, CVec dg, int mode, int n, int n_chains, hipStream_t s);
+
+// ---- update.hip ---------------------------------------------------------------
+struct UpdateTables {            // per chain, 64 doubles: model constants the slice kernel needs
+    // rb[old][k]   = (gamma[new]/gamma[old]) * exp(alpha*g*(eta[new]-eta[old]))   (source/model.cpp:99-122)
+    // delta[old][k]= 1/bosonR - 1
+    // ev[f] = exp(g*eta[f]), iev[f] = exp(-g*eta[f])
+    double rb[4][3];
+    double delta[4][3];
+    double ev[4];
+    double iev[4];
+    double pad[32];
+};
+struct UpdateDesc {
+    Mat G;                        // current Green's function (n*n per chain)
+    int8_t* fields; long f_stride;            // [chain][nt][n]
+    double* expv; double* invexpv; long v_stride;   // [chain][nt][n]
+    const UpdateTables* tabs;                 // [chain]
+    const int32_t* perm; const uint8_t* kprop; const double* u; long rs_stride;  // random stream [chain][nt][n]
+    double* Upanel; double* Wpanel; long panel_stride;   // [chain][KD][n]
+    int* state; long state_stride;            // per chain: [0]=pos, [1]=k (accepts in current window), [2]=accepted in slice
+    int* acc_out; long acc_stride;            // per chain per slice accepted counts [chain][2*nt] (+ offset chosen by caller)
+    int n, nt;
+};
+constexpr int UPDATE_KD = 32;    // delayed-update window (accepted flips per flush)
+// one slice = reset + windows x (scan kernel, flush kernel)
+int launch_update_slice(const UpdateDesc& d, int l, int acc_slot, int n_chains, hipStream_t s);
+// standalone Sherman-Morrison rank-1 update (source/model.cpp:124-138), whole-chip streaming kernel
+int launch_rank1(Mat G, int i, double delta, double* scratch /*2n+1 doubles per chain*/, long scratch_stride, int n, int n_chains, hipStream_t s);
+
+}  // namespace dq

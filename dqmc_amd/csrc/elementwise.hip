@@ -1,0 +1,190 @@
+// elementwise.hip -- small batched memory-bound helpers around the GEMM chain.
+//
+// These carry the O(N^2) passes of the reference that are not fused into a
+// GEMM epilogue: expV tables (source/model.cpp:62-84), the D_large/D_small
+// split (source/stablelinalg.cpp:100-108), identity, copies, transposes, the
+// TermA + TermB sum (:151) and the wrap-vs-stabilised max|dG|
+// (DQMC::check_error, source/dqmc.cpp:317-329).  blockIdx.y = chain.
+#include "common.h"
+
+namespace dq {
+
+__global__ void build_expv_kernel(const int8_t* fields, long f_stride, long total, const double* tab,
+                                  double* expv, double* invexpv, long v_stride) {
+    const int c = blockIdx.y;
+    const double* t = tab + (long)c * 8;
+    for (long k = blockIdx.x * (long)blockDim.x + threadIdx.x; k < total; k += (long)gridDim.x * blockDim.x) {
+        const int f = fields[(long)c * f_stride + k] & 3;
+        expv[(long)c * v_stride + k] = t[f];
+        invexpv[(long)c * v_stride + k] = t[4 + f];
+    }
+}
+int launch_build_expv(const int8_t* fields, long f_stride, int nt, int n, const double* tab, double* expv, double* invexpv,
+                      long v_stride, int n_chains, hipStream_t s) {
+    const long total = (long)nt * n;
+    dim3 grid((unsigned)((total + 255) / 256 > 512 ? 512 : (total + 255) / 256), n_chains);
+    hipLaunchKernelGGL(build_expv_kernel, grid, dim3(256), 0, s, fields, f_stride, total, tab, expv, invexpv, v_stride);
+    DQ_HIP(hipGetLastError());
+    return 0;
+}
+
+// one block of 256 threads per chain
+__global__ void split_d_kernel(CVec d, Vec dl_inv, Vec ds, double* logsum, int n) {
+    const int c = blockIdx.y;
+    const double* dd = d.at(c);
+    double ls = 0.0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const double v = dd[i];
+        const bool large = v >= 1.0;
+        dl_inv.at(c)[i] = large ? 1.0 / v : 1.0;
+        ds.at(c)[i] = large ? 1.0 : v;
+        if (large) ls += log(v);
+    }
+    if (logsum) {
+        __shared__ double red[256];
+        red[threadIdx.x] = ls;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+        if (threadIdx.x == 0) logsum[c] = red[0];
+    }
+}
+int launch_split_d(CVec d, Vec dl_inv, Vec ds, double* logsum, int n, int n_chains, hipStream_t s) {
+    hipLaunchKernelGGL(split_d_kernel, dim3(1, n_chains), dim3(256), 0, s, d, dl_inv, ds, logsum, n);
+    DQ_HIP(hipGetLastError());
+    return 0;
+}
+
+__global__ void copy_kernel(CMat in, Mat out, long count) {
+    const int c = blockIdx.y;
+    const double* a = in.at(c); double* b = out.at(c);
+    for (long k = blockIdx.x * (long)blockDim.x + threadIdx.x; k < count; k += (long)gridDim.x * blockDim.x) b[k] = a[k];
+}
+int launch_copy(CMat in, Mat out, long count, int n_chains, hipStream_t s) {
+    long blocks = (count + 255) / 256; if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(copy_kernel, dim3((unsigned)blocks, n_chains), dim3(256), 0, s, in, out, count);
+    DQ_HIP(hipGetLastError());
+    return 0;
+}
+
+__global__ void identity_kernel(Mat out, int n) {
+    const int c = blockIdx.y; double* o = out.at(c);
+    const long total = (long)n * n;
+    for (long k = blockIdx.x * (long)blockDim.x + threadIdx.x; k < total; k += (long)gridDim.x * blockDim.x)
+        o[k] = (k % n == k / n) ? 1.0 : 0.0;
+}
+int launch_set_identity(Mat out, int n, int n_chains, hipStream_t s) {
+    long blocks = ((long)n * n + 255) / 256; if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(identity_kernel, dim3((unsigned)blocks, n_chains), dim3(256), 0, s, out, n);
+    DQ_HIP(hipGetLastError());
+    return 0;
+}
+
+// 32x32 LDS-tiled transpose with optional row scale on the OUTPUT rows
+__global__ void transpose_scale_kernel(CMat in, Mat out, CVec rs, int n, int tiles) {
+    __shared__ double tile[32][33];
+    const int c = blockIdx.y;
+    const double* a = in.at(c); double* o = out.at(c);
+    const int ti = blockIdx.x % tiles, tj = blockIdx.x / tiles;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        const int i = ti * 32 + tx, j = tj * 32 + r;
+        tile[r][tx] = (i < n && j < n) ? a[i + (long)n * j] : 0.0;    // tile[jj][ii] = in[i][j]
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int i = tj * 32 + tx, j = ti * 32 + r;                  // out[i][j] = in[j][i]
+        if (i < n && j < n) {
+            double v = tile[tx][r];
+            if (rs.p) v *= rs.at(c)[i];
+            o[i + (long)n * j] = v;
+        }
+    }
+}
+int launch_transpose_scale(CMat in, Mat out, CVec rs, int n, int n_chains, hipStream_t s) {
+    const int tiles = (n + 31) / 32;
+    hipLaunchKernelGGL(transpose_scale_kernel, dim3(tiles * tiles, n_chains), dim3(256), 0, s, in, out, rs, n, tiles);
+    DQ_HIP(hipGetLastError());
+    return 0;
+}
+
+// single block per chain: max |A - B|
+__global__ void max_abs_diff_kernel(CMat A, CMat B, double* err, long err_stride, int n) {
+    const int c = blockIdx.y;
+    const double* a = A.at(c); const double* b = B.at(c);
+    const long total = (long)n * n;
+    double m = 0.0;
+    for (long k = threadIdx.x; k < total; k += blockDim.x) { const double d = fabs(a[k] - b[k]); m = (d > m || d != d) ? d : m; }
+    __shared__ double red[1024];
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int o = blockDim.x / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { const double x = red[threadIdx.x + o]; if (x > red[threadIdx.x] || x != x) red[threadIdx.x] = x; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) err[(long)c * err_stride] = red[0];
+}
+int launch_max_abs_diff(CMat A, CMat B, double* err, long err_stride, int n, int n_chains, hipStream_t s) {
+    hipLaunchKernelGGL(max_abs_diff_kernel, dim3(1, n_chains), dim3(1024), 0, s, A, B, err, err_stride, n);
+    DQ_HIP(hipGetLastError());
+    return 0;
+}
+
+__global__ void add_scaled_cols_kernel(CMat A, CMat B, CVec cs, Mat C, int n) {
+    const int c = blockIdx.y;
+    const double* a = A.at(c); const double* b = B.at(c); double* o = C.at(c);
+    const long total = (long)n * n;
+    for (long k = blockIdx.x * (long)blockDim.x + threadIdx.x; k < total; k += (long)gridDim.x * blockDim.x) {
+        double bv = b[k];
+        if (cs.p) bv *= cs.at(c)[k / n];
+        o[k] = a[k] + bv;
+    }
+}
+int launch_add_scaled_cols(CMat A, CMat B, CVec cs, Mat C, int n, int n_chains, hipStream_t s) {
+    const long total = (long)n * n;
+    long blocks = (total + 255) / 256; if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(add_scaled_cols_kernel, dim3((unsigned)blocks, n_chains), dim3(256), 0, s, A, B, cs, C, n);
+    DQ_HIP(hipGetLastError());
+    return 0;
+}
+
+__global__ void scale_rows_kernel(CMat in, CVec rs, Mat out, int n) {
+    const int c = blockIdx.y;
+    const double* a = in.at(c); double* o = out.at(c); const double* r = rs.at(c);
+    const long total = (long)n * n;
+    for (long k = blockIdx.x * (long)blockDim.x + threadIdx.x; k < total; k += (long)gridDim.x * blockDim.x) o[k] = a[k] * r[k % n];
+}
+int launch_scale_rows(CMat in, CVec rs, Mat out, int n, int n_chains, hipStream_t s) {
+    const long total = (long)n * n;
+    long blocks = (total + 255) / 256; if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(scale_rows_kernel, dim3((unsigned)blocks, n_chains), dim3(256), 0, s, in, rs, out, n);
+    DQ_HIP(hipGetLastError());
+    return 0;
+}
+
+// DQMC::acc_rate_ += acc_l / nt per slice (source/dqmc.cpp:366,424); check_error's running
+// max / sum / count (source/dqmc.cpp:324-326).  One thread per chain: the sums are tiny.
+__global__ void fold_stats_kernel(DevStats* st, const int* acc, long acc_stride, int n_slices, const double* err, long err_stride,
+                                  int n_err, int n, int nt, int n_chains) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_chains) return;
+    DevStats s = st[c];
+    for (int k = 0; k < n_slices; ++k) {
+        const int a = acc[(long)c * acc_stride + k];
+        s.acc_rate += (static_cast<double>(a) / n) / nt;
+        s.n_accepted += a; s.n_proposed += n;
+    }
+    for (int k = 0; k < n_err; ++k) {
+        const double e = err[(long)c * err_stride + k];
+        if (e > s.max_err || e != e) s.max_err = e;
+        s.sum_err += e; s.n_err += 1.0;
+    }
+    st[c] = s;
+}
+int launch_fold_stats(DevStats* st, const int* acc, long acc_stride, int n_slices, const double* err, long err_stride, int n_err,
+                      int n, int nt, int n_chains, hipStream_t s) {
+    hipLaunchKernelGGL(fold_stats_kernel, dim3((n_chains + 63) / 64), dim3(64), 0, s, st, acc, acc_stride, n_slices, err, err_stride, n_err, n, nt, n_chains);
+    DQ_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace dq

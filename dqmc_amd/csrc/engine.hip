@@ -1,0 +1,645 @@
+// engine.hip -- the sweep engine (class DQMC of the reference, include/dqmc.h:21-93,
+// source/dqmc.cpp) and the C ABI of include/dqmc_hip.h.
+//
+// An engine owns n_chains independent Markov chains on one GPU; every kernel
+// launch advances all of them (blockIdx.y = chain).  All state lives in HBM
+// across calls: fields (int8, slice-major), the per-slice exp(+-g*eta) vectors,
+// the LDR stack, the current equal-time G and the workspaces.  The host only
+// enqueues: a half sweep is one asynchronous stream of launches with no host
+// round trip; acceptance decisions, pivoting and error checks happen on device.
+#include "common.h"
+#include "../../include/dqmc_hip.h"
+
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <vector>
+
+namespace dq {
+
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+const char* get_error() { return g_err.c_str(); }
+
+#define DQ_TRY(expr)            \
+    do {                        \
+        int _rc = (expr);       \
+        if (_rc != 0) return _rc; \
+    } while (0)
+
+// ---------------------------------------------------------------------------
+// Workspace + stable linear algebra on device (stablelinalg.cpp restated as
+// launch sequences).  Shared by the engine and the stateless ABI calls.
+// ---------------------------------------------------------------------------
+struct LdrRef {                 // a batched LDR triple in HBM
+    Mat L; Vec d; Mat R;
+};
+
+struct Ctx {
+    int n = 0, C = 0, device = 0;
+    long nn = 0;
+    hipStream_t stream = nullptr;
+    static constexpr int NT = 10;              // workspace matrices
+    double* pool = nullptr;                    // NT * C * nn
+    double* vpool = nullptr;                   // vectors: 8 * C * n
+    int* ipool = nullptr;                      // 2 * C * n ints + info
+    double* spool = nullptr;                   // scalars: 4 * C
+
+    Mat T(int k) const { return Mat{pool + (long)k * C * nn, nn}; }
+    Vec V(int k) const { return Vec{vpool + (long)k * C * n, (long)n}; }
+    int* jpvt() const { return ipool; }
+    int* lperm() const { return ipool + (long)C * n; }
+    int* info() const { return ipool + 2L * C * n; }
+    double* logsum() const { return spool; }           // C
+    double* scal(int k) const { return spool + (long)k * C; }
+
+    int init(int n_, int C_, int device_) {
+        n = n_; C = C_; device = device_; nn = (long)n * n;
+        DQ_HIP(hipSetDevice(device));
+        DQ_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        DQ_HIP(hipMalloc(&pool, sizeof(double) * NT * C * nn));
+        DQ_HIP(hipMalloc(&vpool, sizeof(double) * 8 * C * n));
+        DQ_HIP(hipMalloc(&ipool, sizeof(int) * (2L * C * n + 4)));
+        DQ_HIP(hipMalloc(&spool, sizeof(double) * 4 * C));
+        DQ_HIP(hipMemsetAsync(ipool, 0, sizeof(int) * (2L * C * n + 4), stream));
+        return 0;
+    }
+    ~Ctx() {
+        if (pool) (void)hipFree(pool);
+        if (vpool) (void)hipFree(vpool);
+        if (ipool) (void)hipFree(ipool);
+        if (spool) (void)hipFree(spool);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+
+    int gemm(CMat A, CMat B, Mat Cm, CVec rs = CVec(), CVec ks = CVec(), CVec cs = CVec(), int transA = 0, int accumulate = 0) {
+        GemmDesc g; g.A = A; g.B = B; g.C = Cm; g.rs = rs; g.ks = ks; g.cs = cs; g.n = n; g.transA = transA; g.accumulate = accumulate;
+        return launch_gemm(g, C, stream);
+    }
+    // stablelinalg::to_LDR (source/stablelinalg.cpp:35-55); A is destroyed
+    int to_ldr(Mat A, LdrRef out) {
+        QrWork w{V(7).p, (long)n, jpvt(), (long)n};
+        return launch_to_ldr(A, out.L, out.d, out.R, w, n, C, stream);
+    }
+    // stablelinalg::mat_mul_ldr (source/stablelinalg.cpp:69-79): out = M * F   (uses T0,T1)
+    int mat_mul_ldr(CMat M, LdrRef F, LdrRef out) {
+        DQ_TRY(gemm(M, F.L, T(0), CVec(), CVec(), CVec(F.d)));           // (M L) diag(d)
+        LdrRef q{out.L, out.d, T(1)};
+        DQ_TRY(to_ldr(T(0), q));
+        return gemm(T(1), F.R, out.R);                                   // r * R
+    }
+    // stablelinalg::ldr_mul_mat (source/stablelinalg.cpp:57-67): out = F * M   (uses T0,T1)
+    int ldr_mul_mat(LdrRef F, CMat M, LdrRef out) {
+        DQ_TRY(gemm(F.R, M, T(0), CVec(F.d)));                            // diag(d) (R M)
+        LdrRef q{T(1), out.d, out.R};
+        DQ_TRY(to_ldr(T(0), q));
+        return gemm(F.L, T(1), out.L);                                   // L * q
+    }
+    // stablelinalg::ldr_mul_ldr (source/stablelinalg.cpp:81-92): out = F1 * F2   (uses T0,T1,T2)
+    int ldr_mul_ldr(LdrRef F1, LdrRef F2, LdrRef out) {
+        DQ_TRY(gemm(F1.R, F2.L, T(0), CVec(F1.d), CVec(), CVec(F2.d)));    // diag(d1) (R1 L2) diag(d2)
+        LdrRef q{T(1), out.d, T(2)};
+        DQ_TRY(to_ldr(T(0), q));
+        DQ_TRY(gemm(F1.L, T(1), out.L));
+        return gemm(T(2), F2.R, out.R);
+    }
+    // stablelinalg::inv_I_plus_ldr (source/stablelinalg.cpp:94-126)   (uses T0..T4, V0,V1)
+    // G = X M^-1 is evaluated as the reference does, through the transposed system M^T G^T = X^T;
+    // log|det M| comes from that same factorisation (det M^T = det M).
+    int inv_I_plus_ldr(LdrRef F, Mat G, double* logdet /*device, C*/) {
+        DQ_TRY(launch_split_d(F.d, V(0), V(1), logdet, n, C, stream));                 // V0 = 1/Dl, V1 = Ds, logdet = sum log Dl
+        DQ_TRY(launch_copy(F.R, T(0), nn, C, stream));
+        DQ_TRY(launch_lu(T(0), lperm(), n, nullptr, 0, info(), n, C, stream));
+        DQ_TRY(launch_lu_solve(T(0), lperm(), n, T(1), V(0), 1, n, C, stream));         // X = R^-1 diag(1/Dl)
+        DQ_TRY(launch_add_scaled_cols(T(1), F.L, V(1), T(2), n, C, stream));            // M = X + L diag(Ds)
+        DQ_TRY(launch_transpose_scale(T(2), T(3), CVec(), n, C, stream));               // M^T
+        DQ_TRY(launch_lu(T(3), lperm(), n, logdet, 1, info(), n, C, stream));           // logdet += log|det M|
+        DQ_TRY(launch_transpose_scale(T(1), T(4), CVec(), n, C, stream));               // X^T
+        DQ_TRY(launch_lu_solve(T(3), lperm(), n, T(4), CVec(), 0, n, C, stream));       // G^T
+        return launch_transpose_scale(T(4), G, CVec(), n, C, stream);
+    }
+    // stablelinalg::inv_I_plus_ldr_mul_ldr (source/stablelinalg.cpp:128-158)   (uses T0..T3, V0..V3)
+    int inv_I_plus_ldr_mul_ldr(LdrRef F1, LdrRef F2, Mat G) {
+        DQ_TRY(launch_split_d(F1.d, V(0), V(1), nullptr, n, C, stream));               // 1/D1l, D1s
+        DQ_TRY(launch_split_d(F2.d, V(2), V(3), nullptr, n, C, stream));               // 1/D2l, D2s
+        DQ_TRY(launch_copy(F2.R, T(0), nn, C, stream));
+        DQ_TRY(launch_lu(T(0), lperm(), n, nullptr, 0, info(), n, C, stream));
+        DQ_TRY(launch_lu_solve(T(0), lperm(), n, T(1), V(2), 1, n, C, stream));         // X = R2^-1 diag(1/D2l)
+        DQ_TRY(gemm(F1.L, T(1), T(2), V(0), CVec(), CVec(), 1));                        // TermA = diag(1/D1l) L1^T X
+        DQ_TRY(gemm(F1.R, F2.L, T(2), V(1), CVec(), V(3), 0, 1));                       // M = TermA + diag(D1s) R1 L2 diag(D2s)
+        DQ_TRY(launch_transpose_scale(F1.L, T(3), V(0), n, C, stream));                 // RHS = diag(1/D1l) L1^T
+        DQ_TRY(launch_lu(T(2), lperm(), n, nullptr, 0, info(), n, C, stream));
+        DQ_TRY(launch_lu_solve(T(2), lperm(), n, T(3), CVec(), 0, n, C, stream));       // Y = M^-1 RHS
+        return gemm(T(1), T(3), G);                                                     // G = X Y
+    }
+};
+
+// ---------------------------------------------------------------------------
+// Engine
+// ---------------------------------------------------------------------------
+struct Engine {
+    int n = 0, nt = 0, n_stab = 0, n_stack = 0, C = 1, device = 0;
+    long nn = 0;
+    std::vector<int> loc_l_end;
+    std::vector<double> g_host, gamma_host, eta_host;
+    Ctx ctx;
+    hipStream_t s = nullptr;
+
+    double* expK = nullptr; double* invexpK = nullptr;           // [C][nn]
+    int8_t* fields = nullptr;                                    // [C][nt][n]
+    double* expv = nullptr; double* invexpv = nullptr;           // [C][nt][n]
+    UpdateTables* tabs = nullptr; double* tab8 = nullptr;        // [C], [C][8]
+    double* G = nullptr; double* Gtmp = nullptr;                 // [C][nn]
+    double* bb0 = nullptr; double* bb1 = nullptr;                // Bbar ping-pong
+    double* stackL = nullptr; double* stackD = nullptr; double* stackR = nullptr;
+    double* tmpL = nullptr; double* tmpD = nullptr; double* tmpR = nullptr;   // one spare LDR (init_stacks)
+    double* logdet = nullptr;                                    // [C]
+    int32_t* rs_perm = nullptr; uint8_t* rs_k = nullptr; double* rs_u = nullptr;   // [C][nt][n]
+    void* h_stage = nullptr; size_t h_stage_bytes = 0;           // pinned staging for the random stream
+    hipEvent_t stage_free = nullptr;
+    double* Upanel = nullptr; double* Wpanel = nullptr;          // [C][KD][n]
+    int* state = nullptr;                                        // [C][4]
+    int* acc = nullptr;                                          // [C][nt]
+    double* err = nullptr;                                       // [C][n_stack]
+    DevStats* dstats = nullptr;                                  // [C]
+    double* r1scratch = nullptr;
+    bool stack_valid = false;
+    // profiling of the local-update kernels
+    bool profiling = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pairs;
+    size_t ev_used = 0;
+    double upd_ms = 0.0; long long upd_launches = 0; long long upd_accept_base = 0;
+
+    Mat mG() const { return Mat{G, nn}; }
+    LdrRef stk(int i) const { return LdrRef{Mat{stackL + (long)i * C * nn, nn}, Vec{stackD + (long)i * C * n, (long)n}, Mat{stackR + (long)i * C * nn, nn}}; }
+    CVec ev(int l) const { return CVec(expv + (long)l * n, (long)nt * n); }
+    CVec iev(int l) const { return CVec(invexpv + (long)l * n, (long)nt * n); }
+    int stack_idx(int l) const { return l / n_stab; }            // include/dqmc.h:47
+    int local_l(int l) const { return l % n_stab; }              // include/dqmc.h:48
+
+    ~Engine() {
+        if (s) (void)hipStreamSynchronize(s);
+        for (auto& p : ev_pairs) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+        if (stage_free) (void)hipEventDestroy(stage_free);
+        void* ptrs[] = {expK, invexpK, fields, expv, invexpv, tabs, tab8, G, Gtmp, bb0, bb1, stackL, stackD, stackR, tmpL, tmpD, tmpR,
+                        logdet, rs_perm, rs_k, rs_u, Upanel, Wpanel, state, acc, err, dstats, r1scratch};
+        for (void* p : ptrs) if (p) (void)hipFree(p);
+        if (h_stage) (void)hipHostFree(h_stage);
+    }
+
+    template <class T> int dalloc(T** p, size_t count) { DQ_HIP(hipMalloc(reinterpret_cast<void**>(p), sizeof(T) * count)); return 0; }
+
+    int create(int device_, int C_, int n_, int nt_, int n_stab_, const double* g, const double* gamma, const double* eta,
+               const double* eK, const double* ieK) {
+        device = device_; C = C_; n = n_; nt = nt_; n_stab = n_stab_; nn = (long)n * n;
+        n_stack = (int)std::ceil(static_cast<double>(nt) / n_stab);                       // source/dqmc.cpp:10
+        loc_l_end.assign(n_stack, n_stab - 1);
+        if (nt % n_stab != 0) loc_l_end[n_stack - 1] = nt % n_stab - 1;                    // source/dqmc.cpp:13-18
+        g_host.assign(g, g + C); gamma_host.assign(gamma, gamma + 4); eta_host.assign(eta, eta + 4);
+        DQ_TRY(ctx.init(n, C, device)); s = ctx.stream;
+        DQ_TRY(dalloc(&expK, C * nn)); DQ_TRY(dalloc(&invexpK, C * nn));
+        DQ_TRY(dalloc(&fields, (size_t)C * nt * n)); DQ_TRY(dalloc(&expv, (size_t)C * nt * n)); DQ_TRY(dalloc(&invexpv, (size_t)C * nt * n));
+        DQ_TRY(dalloc(&tabs, C)); DQ_TRY(dalloc(&tab8, (size_t)C * 8));
+        DQ_TRY(dalloc(&G, C * nn)); DQ_TRY(dalloc(&Gtmp, C * nn)); DQ_TRY(dalloc(&bb0, C * nn)); DQ_TRY(dalloc(&bb1, C * nn));
+        DQ_TRY(dalloc(&stackL, (size_t)n_stack * C * nn)); DQ_TRY(dalloc(&stackD, (size_t)n_stack * C * n)); DQ_TRY(dalloc(&stackR, (size_t)n_stack * C * nn));
+        DQ_TRY(dalloc(&tmpL, C * nn)); DQ_TRY(dalloc(&tmpD, (size_t)C * n)); DQ_TRY(dalloc(&tmpR, C * nn));
+        DQ_TRY(dalloc(&logdet, C));
+        DQ_TRY(dalloc(&rs_perm, (size_t)C * nt * n)); DQ_TRY(dalloc(&rs_k, (size_t)C * nt * n)); DQ_TRY(dalloc(&rs_u, (size_t)C * nt * n));
+        DQ_TRY(dalloc(&Upanel, (size_t)C * UPDATE_KD * n)); DQ_TRY(dalloc(&Wpanel, (size_t)C * UPDATE_KD * n));
+        DQ_TRY(dalloc(&state, (size_t)C * 4)); DQ_TRY(dalloc(&acc, (size_t)C * nt)); DQ_TRY(dalloc(&err, (size_t)C * n_stack));
+        DQ_TRY(dalloc(&dstats, C)); DQ_TRY(dalloc(&r1scratch, (size_t)C * (2 * n + 1)));
+        h_stage_bytes = (size_t)C * nt * n * (sizeof(int32_t) + sizeof(uint8_t) + sizeof(double));
+        DQ_HIP(hipHostMalloc(&h_stage, h_stage_bytes, hipHostMallocDefault));
+        DQ_HIP(hipEventCreateWithFlags(&stage_free, hipEventDisableTiming));
+        DQ_HIP(hipEventRecord(stage_free, s));
+        DQ_HIP(hipMemcpyAsync(expK, eK, sizeof(double) * C * nn, hipMemcpyHostToDevice, s));
+        DQ_HIP(hipMemcpyAsync(invexpK, ieK, sizeof(double) * C * nn, hipMemcpyHostToDevice, s));
+        DQ_HIP(hipMemsetAsync(fields, 0, (size_t)C * nt * n, s));
+        DQ_HIP(hipMemsetAsync(G, 0, sizeof(double) * C * nn, s));
+        DQ_HIP(hipMemsetAsync(dstats, 0, sizeof(DevStats) * C, s));
+        DQ_HIP(hipMemsetAsync(logdet, 0, sizeof(double) * C, s));
+        DQ_HIP(hipMemsetAsync(state, 0, sizeof(int) * C * 4, s));
+        // model tables, same expressions as source/model.cpp:99-122, :62-84
+        std::vector<UpdateTables> ht(C); std::vector<double> h8((size_t)C * 8);
+        static const int proposal[4][3] = {{1, 2, 3}, {0, 2, 3}, {0, 1, 3}, {0, 1, 2}};
+        const double alpha = -1.0;
+        for (int c = 0; c < C; ++c) {
+            std::memset(&ht[c], 0, sizeof(UpdateTables));
+            for (int o = 0; o < 4; ++o) for (int k = 0; k < 3; ++k) {
+                const int nf = proposal[o][k];
+                const double gammaR = gamma[nf] / gamma[o];
+                const double d_eta = eta[nf] - eta[o];
+                const double bosonR = std::exp(alpha * g[c] * d_eta);
+                ht[c].rb[o][k] = gammaR * bosonR;
+                ht[c].delta[o][k] = (1.0 / bosonR) - 1.0;
+            }
+            for (int f = 0; f < 4; ++f) { ht[c].ev[f] = std::exp(g[c] * eta[f]); ht[c].iev[f] = std::exp(-g[c] * eta[f]); h8[(size_t)c * 8 + f] = ht[c].ev[f]; h8[(size_t)c * 8 + 4 + f] = ht[c].iev[f]; }
+        }
+        DQ_HIP(hipMemcpyAsync(tabs, ht.data(), sizeof(UpdateTables) * C, hipMemcpyHostToDevice, s));
+        DQ_HIP(hipMemcpyAsync(tab8, h8.data(), sizeof(double) * C * 8, hipMemcpyHostToDevice, s));
+        DQ_TRY(launch_build_expv(fields, (long)nt * n, nt, n, tab8, expv, invexpv, (long)nt * n, C, s));
+        DQ_HIP(hipStreamSynchronize(s));
+        return 0;
+    }
+
+    // DQMC::calculate_Bbar (source/dqmc.cpp:88-105) without the multiply by I: result in *out
+    int Bbar(int is, Mat* out) {
+        const int l0 = is * n_stab;
+        Mat cur{bb0, nn}, nxt{bb1, nn};
+        DQ_TRY(launch_scale_rows(CMat(expK, nn), ev(l0), cur, n, C, s));                  // B_l0 = diag(expV) expK
+        for (int loc = 1; loc <= loc_l_end[is]; ++loc) {
+            DQ_TRY(ctx.gemm(CMat(expK, nn), cur, nxt, ev(l0 + loc)));                     // B_l * Bbar
+            std::swap(cur, nxt);
+        }
+        *out = cur; return 0;
+    }
+    // DQMC::init_stacks + init_greenfunctions (source/dqmc.cpp:43-72)
+    int init() {
+        LdrRef tmp{Mat{tmpL, nn}, Vec{tmpD, (long)n}, Mat{tmpR, nn}};
+        for (int i = n_stack - 1; i >= 0; --i) {
+            Mat bb; DQ_TRY(Bbar(i, &bb));
+            if (i == n_stack - 1) DQ_TRY(ctx.to_ldr(bb, stk(i)));
+            else { DQ_TRY(ctx.to_ldr(bb, tmp)); DQ_TRY(ctx.ldr_mul_ldr(stk(i + 1), tmp, stk(i))); }
+        }
+        stack_valid = true;
+        return ctx.inv_I_plus_ldr(stk(0), mG(), logdet);
+    }
+    // DQMC::propagate_GF_forward (source/dqmc.cpp:113-132): G = B_l G B_l^-1
+    int wrap_forward(int l) {
+        DQ_TRY(ctx.gemm(CMat(expK, nn), mG(), ctx.T(0)));
+        return ctx.gemm(ctx.T(0), CMat(invexpK, nn), mG(), ev(l), CVec(), iev(l));
+    }
+    // DQMC::propagate_GF_backward (source/dqmc.cpp:169-187): G = B_l^-1 G B_l
+    int wrap_backward(int l) {
+        DQ_TRY(ctx.gemm(CMat(invexpK, nn), mG(), ctx.T(0), CVec(), iev(l)));
+        return ctx.gemm(ctx.T(0), CMat(expK, nn), mG(), CVec(), ev(l));
+    }
+    UpdateDesc udesc() const {
+        UpdateDesc d; d.G = mG(); d.fields = fields; d.f_stride = (long)nt * n; d.expv = expv; d.invexpv = invexpv; d.v_stride = (long)nt * n;
+        d.tabs = tabs; d.perm = rs_perm; d.kprop = rs_k; d.u = rs_u; d.rs_stride = (long)nt * n; d.Upanel = Upanel; d.Wpanel = Wpanel;
+        d.panel_stride = (long)UPDATE_KD * n; d.state = state; d.state_stride = 4; d.acc_out = acc; d.acc_stride = nt; d.n = n; d.nt = nt;
+        return d;
+    }
+    int local_update(int l) {
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (profiling) {
+            if (ev_used == ev_pairs.size()) { hipEvent_t a, b; DQ_HIP(hipEventCreate(&a)); DQ_HIP(hipEventCreate(&b)); ev_pairs.emplace_back(a, b); }
+            e0 = ev_pairs[ev_used].first; e1 = ev_pairs[ev_used].second; ++ev_used;
+            DQ_HIP(hipEventRecord(e0, s));
+        }
+        DQ_TRY(launch_update_slice(udesc(), l, l, C, s));
+        if (profiling) DQ_HIP(hipEventRecord(e1, s));
+        return 0;
+    }
+    int upload_stream(const int32_t* perm, const uint8_t* kprop, const double* u) {
+        const size_t cnt = (size_t)C * nt * n;
+        DQ_HIP(hipEventSynchronize(stage_free));                   // previous H2D copies out of the staging buffer are done
+        char* base = static_cast<char*>(h_stage);
+        double* hu = reinterpret_cast<double*>(base);
+        int32_t* hp = reinterpret_cast<int32_t*>(base + cnt * sizeof(double));
+        uint8_t* hk = reinterpret_cast<uint8_t*>(base + cnt * (sizeof(double) + sizeof(int32_t)));
+        std::memcpy(hu, u, cnt * sizeof(double)); std::memcpy(hp, perm, cnt * sizeof(int32_t)); std::memcpy(hk, kprop, cnt);
+        DQ_HIP(hipMemcpyAsync(rs_u, hu, cnt * sizeof(double), hipMemcpyHostToDevice, s));
+        DQ_HIP(hipMemcpyAsync(rs_perm, hp, cnt * sizeof(int32_t), hipMemcpyHostToDevice, s));
+        DQ_HIP(hipMemcpyAsync(rs_k, hk, cnt, hipMemcpyHostToDevice, s));
+        DQ_HIP(hipEventRecord(stage_free, s));
+        return 0;
+    }
+    // DQMC::sweep_0_to_beta (source/dqmc.cpp:337-396)
+    int sweep_fwd() {
+        int n_err = 0;
+        for (int l = 0; l < nt; ++l) {
+            DQ_TRY(wrap_forward(l));
+            DQ_TRY(local_update(l));
+            const int is = stack_idx(l);
+            if (local_l(l) == loc_l_end[is]) {
+                DQ_TRY(launch_copy(mG(), Mat{Gtmp, nn}, nn, C, s));
+                Mat bb; DQ_TRY(Bbar(is, &bb));
+                if (is == 0) DQ_TRY(ctx.to_ldr(bb, stk(0)));                                  // update_stack_forward :134-146
+                else DQ_TRY(ctx.mat_mul_ldr(bb, stk(is - 1), stk(is)));
+                if (l == nt - 1) DQ_TRY(ctx.inv_I_plus_ldr(stk(is), mG(), logdet));           // stabilize_GF_forward :148-161
+                else DQ_TRY(ctx.inv_I_plus_ldr_mul_ldr(stk(is), stk(is + 1), mG()));
+                DQ_TRY(launch_max_abs_diff(CMat(Gtmp, nn), mG(), err + n_err, n_stack, n, C, s));   // check_error :317-329
+                ++n_err;
+            }
+        }
+        return launch_fold_stats(dstats, acc, nt, nt, err, n_stack, n_err, n, nt, C, s);
+    }
+    // DQMC::sweep_beta_to_0 (source/dqmc.cpp:398-456)
+    int sweep_bwd() {
+        int n_err = 0;
+        for (int l = nt - 1; l >= 0; --l) {
+            DQ_TRY(local_update(l));
+            DQ_TRY(wrap_backward(l));
+            const int is = stack_idx(l);
+            if (local_l(l) == 0) {
+                DQ_TRY(launch_copy(mG(), Mat{Gtmp, nn}, nn, C, s));
+                Mat bb; DQ_TRY(Bbar(is, &bb));
+                if (is == n_stack - 1) DQ_TRY(ctx.to_ldr(bb, stk(is)));                       // update_stack_backward :189-201
+                else DQ_TRY(ctx.ldr_mul_mat(stk(is + 1), bb, stk(is)));
+                if (l == 0) DQ_TRY(ctx.inv_I_plus_ldr(stk(is), mG(), logdet));                // stabilize_GF_backward :203-215
+                else DQ_TRY(ctx.inv_I_plus_ldr_mul_ldr(stk(is - 1), stk(is), mG()));
+                DQ_TRY(launch_max_abs_diff(CMat(Gtmp, nn), mG(), err + n_err, n_stack, n, C, s));
+                ++n_err;
+            }
+        }
+        return launch_fold_stats(dstats, acc, nt, nt, err, n_stack, n_err, n, nt, C, s);
+    }
+    int sync_and_check() {
+        DQ_HIP(hipStreamSynchronize(s));
+        if (profiling && ev_used) {
+            for (size_t k = 0; k < ev_used; ++k) { float ms = 0.f; DQ_HIP(hipEventElapsedTime(&ms, ev_pairs[k].first, ev_pairs[k].second)); upd_ms += ms; }
+            upd_launches += (long long)ev_used; ev_used = 0;
+        }
+        int h_info = 0;
+        DQ_HIP(hipMemcpy(&h_info, ctx.info(), sizeof(int), hipMemcpyDeviceToHost));
+        if (h_info) { set_error("LU factorisation hit a zero or NaN pivot"); (void)hipMemset(ctx.info(), 0, sizeof(int)); return DQMC_ENUMERIC; }
+        return 0;
+    }
+};
+
+// ---- stateless calls: one cached single-chain context per n --------------------------------
+static std::mutex g_ctx_mu;
+static std::map<int, std::unique_ptr<Ctx>> g_ctx;
+static std::map<int, double*> g_ctx_extra;     // 3 LDR triples worth of scratch per n
+
+static int get_ctx(int n, Ctx** out, double** extra) {
+    if (n <= 0) { set_error("n must be positive"); return DQMC_EINVAL; }
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count == 0) { set_error("no HIP device available: this library requires a gfx950 GPU"); return DQMC_ENODEVICE; }
+    auto it = g_ctx.find(n);
+    if (it == g_ctx.end()) {
+        std::unique_ptr<Ctx> c(new Ctx);
+        DQ_TRY(c->init(n, 1, 0));
+        double* ex = nullptr;
+        DQ_HIP(hipMalloc(&ex, sizeof(double) * (8L * n * n + 4L * n)));
+        g_ctx_extra[n] = ex;
+        it = g_ctx.emplace(n, std::move(c)).first;
+    }
+    *out = it->second.get(); *extra = g_ctx_extra[n];
+    return hipSetDevice(0) == hipSuccess ? 0 : DQMC_ENODEVICE;
+}
+struct HostLdr { const double* L; const double* d; const double* R; };
+static int upload_ldr(Ctx* c, double* base, HostLdr h, LdrRef* out) {
+    const long nn = c->nn; const int n = c->n;
+    out->L = Mat{base, nn}; out->R = Mat{base + nn, nn}; out->d = Vec{base + 2 * nn, (long)n};
+    DQ_HIP(hipMemcpyAsync(out->L.p, h.L, sizeof(double) * nn, hipMemcpyHostToDevice, c->stream));
+    DQ_HIP(hipMemcpyAsync(out->R.p, h.R, sizeof(double) * nn, hipMemcpyHostToDevice, c->stream));
+    DQ_HIP(hipMemcpyAsync(out->d.p, h.d, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    return 0;
+}
+static int download_ldr(Ctx* c, LdrRef f, double* L, double* d, double* R) {
+    DQ_HIP(hipMemcpyAsync(L, f.L.p, sizeof(double) * c->nn, hipMemcpyDeviceToHost, c->stream));
+    DQ_HIP(hipMemcpyAsync(R, f.R.p, sizeof(double) * c->nn, hipMemcpyDeviceToHost, c->stream));
+    DQ_HIP(hipMemcpyAsync(d, f.d.p, sizeof(double) * c->n, hipMemcpyDeviceToHost, c->stream));
+    DQ_HIP(hipStreamSynchronize(c->stream));
+    int h_info = 0;
+    DQ_HIP(hipMemcpy(&h_info, c->info(), sizeof(int), hipMemcpyDeviceToHost));
+    if (h_info) { set_error("factorisation hit a zero or NaN pivot"); (void)hipMemset(c->info(), 0, sizeof(int)); return DQMC_ENUMERIC; }
+    return 0;
+}
+static LdrRef slot(Ctx* c, double* extra, int k) {     // k = 0,1,2: LDR-sized scratch slots after the two upload slots
+    double* base = extra + (long)k * (2 * c->nn + c->n);
+    return LdrRef{Mat{base, c->nn}, Vec{base + 2 * c->nn, (long)c->n}, Mat{base + c->nn, c->nn}};
+}
+
+}  // namespace dq
+
+using namespace dq;
+
+struct dqmc_engine { Engine e; };
+
+#define API_LOCK std::lock_guard<std::mutex> _lk(g_ctx_mu)
+#define CHECK_E(e) if (!(e)) { set_error("null engine"); return DQMC_EINVAL; }
+
+extern "C" {
+
+const char* dqmc_last_error(void) { return get_error(); }
+const char* dqmc_backend(void) { return "hip:gfx950"; }
+int dqmc_device_count(void) { int c = 0; if (hipGetDeviceCount(&c) != hipSuccess) return 0; return c; }
+
+int dqmc_to_ldr(int n, const double* M, double* L, double* d, double* R) {
+    API_LOCK; Ctx* c; double* ex; DQ_TRY(get_ctx(n, &c, &ex));
+    if (!M || !L || !d || !R) { set_error("null pointer"); return DQMC_EINVAL; }
+    DQ_HIP(hipMemcpyAsync(c->T(5).p, M, sizeof(double) * c->nn, hipMemcpyHostToDevice, c->stream));
+    LdrRef out = slot(c, ex, 0);
+    DQ_TRY(c->to_ldr(c->T(5), out));
+    return download_ldr(c, out, L, d, R);
+}
+int dqmc_ldr_mul_mat(int n, const double* L, const double* d, const double* R, const double* M, double* Lo, double* d_o, double* Ro) {
+    API_LOCK; Ctx* c; double* ex; DQ_TRY(get_ctx(n, &c, &ex));
+    LdrRef F; DQ_TRY(upload_ldr(c, slot(c, ex, 0).L.p, HostLdr{L, d, R}, &F));
+    DQ_HIP(hipMemcpyAsync(c->T(5).p, M, sizeof(double) * c->nn, hipMemcpyHostToDevice, c->stream));
+    LdrRef out = slot(c, ex, 2);
+    DQ_TRY(c->ldr_mul_mat(F, c->T(5), out));
+    return download_ldr(c, out, Lo, d_o, Ro);
+}
+int dqmc_mat_mul_ldr(int n, const double* M, const double* L, const double* d, const double* R, double* Lo, double* d_o, double* Ro) {
+    API_LOCK; Ctx* c; double* ex; DQ_TRY(get_ctx(n, &c, &ex));
+    LdrRef F; DQ_TRY(upload_ldr(c, slot(c, ex, 0).L.p, HostLdr{L, d, R}, &F));
+    DQ_HIP(hipMemcpyAsync(c->T(5).p, M, sizeof(double) * c->nn, hipMemcpyHostToDevice, c->stream));
+    LdrRef out = slot(c, ex, 2);
+    DQ_TRY(c->mat_mul_ldr(c->T(5), F, out));
+    return download_ldr(c, out, Lo, d_o, Ro);
+}
+int dqmc_ldr_mul_ldr(int n, const double* L1, const double* d1, const double* R1, const double* L2, const double* d2, const double* R2, double* Lo, double* d_o, double* Ro) {
+    API_LOCK; Ctx* c; double* ex; DQ_TRY(get_ctx(n, &c, &ex));
+    LdrRef F1, F2; DQ_TRY(upload_ldr(c, slot(c, ex, 0).L.p, HostLdr{L1, d1, R1}, &F1)); DQ_TRY(upload_ldr(c, slot(c, ex, 1).L.p, HostLdr{L2, d2, R2}, &F2));
+    LdrRef out = slot(c, ex, 2);
+    DQ_TRY(c->ldr_mul_ldr(F1, F2, out));
+    return download_ldr(c, out, Lo, d_o, Ro);
+}
+int dqmc_inv_I_plus_ldr(int n, const double* L, const double* d, const double* R, double* G, double* logdet) {
+    API_LOCK; Ctx* c; double* ex; DQ_TRY(get_ctx(n, &c, &ex));
+    LdrRef F; DQ_TRY(upload_ldr(c, slot(c, ex, 0).L.p, HostLdr{L, d, R}, &F));
+    DQ_TRY(c->inv_I_plus_ldr(F, c->T(6), c->scal(1)));
+    DQ_HIP(hipMemcpyAsync(G, c->T(6).p, sizeof(double) * c->nn, hipMemcpyDeviceToHost, c->stream));
+    double ld = 0.0;
+    DQ_HIP(hipMemcpyAsync(&ld, c->scal(1), sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    DQ_HIP(hipStreamSynchronize(c->stream));
+    if (logdet) *logdet = ld;
+    int h_info = 0; DQ_HIP(hipMemcpy(&h_info, c->info(), sizeof(int), hipMemcpyDeviceToHost));
+    if (h_info) { set_error("LU hit a zero or NaN pivot"); (void)hipMemset(c->info(), 0, sizeof(int)); return DQMC_ENUMERIC; }
+    return 0;
+}
+int dqmc_inv_I_plus_ldr_mul_ldr(int n, const double* L1, const double* d1, const double* R1, const double* L2, const double* d2, const double* R2, double* G) {
+    API_LOCK; Ctx* c; double* ex; DQ_TRY(get_ctx(n, &c, &ex));
+    LdrRef F1, F2; DQ_TRY(upload_ldr(c, slot(c, ex, 0).L.p, HostLdr{L1, d1, R1}, &F1)); DQ_TRY(upload_ldr(c, slot(c, ex, 1).L.p, HostLdr{L2, d2, R2}, &F2));
+    DQ_TRY(c->inv_I_plus_ldr_mul_ldr(F1, F2, c->T(6)));
+    DQ_HIP(hipMemcpyAsync(G, c->T(6).p, sizeof(double) * c->nn, hipMemcpyDeviceToHost, c->stream));
+    DQ_HIP(hipStreamSynchronize(c->stream));
+    int h_info = 0; DQ_HIP(hipMemcpy(&h_info, c->info(), sizeof(int), hipMemcpyDeviceToHost));
+    if (h_info) { set_error("LU hit a zero or NaN pivot"); (void)hipMemset(c->info(), 0, sizeof(int)); return DQMC_ENUMERIC; }
+    return 0;
+}
+int dqmc_gemm(int n, const double* A, int transA, const double* B, int transB, double* Cm) {
+    API_LOCK; Ctx* c; double* ex; DQ_TRY(get_ctx(n, &c, &ex));
+    DQ_HIP(hipMemcpyAsync(c->T(5).p, A, sizeof(double) * c->nn, hipMemcpyHostToDevice, c->stream));
+    DQ_HIP(hipMemcpyAsync(c->T(6).p, B, sizeof(double) * c->nn, hipMemcpyHostToDevice, c->stream));
+    CMat Bm = c->T(6);
+    if (transB) { DQ_TRY(launch_transpose_scale(c->T(6), c->T(7), CVec(), n, 1, c->stream)); Bm = c->T(7); }
+    DQ_TRY(c->gemm(c->T(5), Bm, c->T(8), CVec(), CVec(), CVec(), transA ? 1 : 0));
+    DQ_HIP(hipMemcpyAsync(Cm, c->T(8).p, sizeof(double) * c->nn, hipMemcpyDeviceToHost, c->stream));
+    DQ_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+int dqmc_rank1_update(int n, double* G, int i, double delta) {
+    API_LOCK; Ctx* c; double* ex; DQ_TRY(get_ctx(n, &c, &ex));
+    if (i < 0 || i >= n) { set_error("site index out of range"); return DQMC_ERANGE; }
+    DQ_HIP(hipMemcpyAsync(c->T(5).p, G, sizeof(double) * c->nn, hipMemcpyHostToDevice, c->stream));
+    DQ_TRY(launch_rank1(c->T(5), i, delta, c->T(6).p, 2L * n + 1, n, 1, c->stream));
+    DQ_HIP(hipMemcpyAsync(G, c->T(5).p, sizeof(double) * c->nn, hipMemcpyDeviceToHost, c->stream));
+    DQ_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int dqmc_create_batch(dqmc_engine** out, int device, int n_chains, int n_sites, int nt, int n_stab, const double* g,
+                      const double gamma[4], const double eta[4], const double* expK, const double* invexpK) {
+    if (!out || n_chains <= 0 || n_sites <= 0 || nt <= 0 || n_stab <= 0 || !g || !gamma || !eta || !expK || !invexpK) { set_error("bad argument"); return DQMC_EINVAL; }
+    if (n_sites > 1024) { set_error("n_sites > 1024 is not supported by the single-workgroup kernels"); return DQMC_EINVAL; }
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count == 0) { set_error("no HIP device available: this library requires a gfx950 GPU"); return DQMC_ENODEVICE; }
+    if (device < 0 || device >= count) { set_error("device ordinal out of range"); return DQMC_EINVAL; }
+    dqmc_engine* h = new (std::nothrow) dqmc_engine;
+    if (!h) return DQMC_ENOMEM;
+    int rc = h->e.create(device, n_chains, n_sites, nt, n_stab, g, gamma, eta, expK, invexpK);
+    if (rc) { delete h; return rc; }
+    *out = h; return 0;
+}
+int dqmc_create(dqmc_engine** out, int device, int n_sites, int nt, int n_stab, double g, const double gamma[4], const double eta[4],
+                const double* expK, const double* invexpK) {
+    return dqmc_create_batch(out, device, 1, n_sites, nt, n_stab, &g, gamma, eta, expK, invexpK);
+}
+void dqmc_destroy(dqmc_engine* h) { if (h) { (void)hipSetDevice(h->e.device); delete h; } }
+int dqmc_n_chains(dqmc_engine* h) { return h ? h->e.C : 0; }
+
+int dqmc_set_fields(dqmc_engine* h, const int64_t* f) {
+    CHECK_E(h); Engine& e = h->e; DQ_HIP(hipSetDevice(e.device));
+    std::vector<int8_t> tmp((size_t)e.C * e.nt * e.n);
+    for (int c = 0; c < e.C; ++c) for (int i = 0; i < e.n; ++i) for (int l = 0; l < e.nt; ++l) {
+        const int64_t v = f[(size_t)c * e.nt * e.n + l + (size_t)e.nt * i];
+        if (v < 0 || v > 3) { set_error("field value outside {0,1,2,3}"); return DQMC_EINVAL; }
+        tmp[(size_t)c * e.nt * e.n + (size_t)l * e.n + i] = (int8_t)v;
+    }
+    DQ_HIP(hipStreamSynchronize(e.s));
+    DQ_HIP(hipMemcpy(e.fields, tmp.data(), tmp.size(), hipMemcpyHostToDevice));
+    DQ_TRY(launch_build_expv(e.fields, (long)e.nt * e.n, e.nt, e.n, e.tab8, e.expv, e.invexpv, (long)e.nt * e.n, e.C, e.s));
+    DQ_HIP(hipStreamSynchronize(e.s));
+    return 0;
+}
+int dqmc_get_fields(dqmc_engine* h, int64_t* f) {
+    CHECK_E(h); Engine& e = h->e; DQ_HIP(hipSetDevice(e.device));
+    DQ_TRY(e.sync_and_check());
+    std::vector<int8_t> tmp((size_t)e.C * e.nt * e.n);
+    DQ_HIP(hipMemcpy(tmp.data(), e.fields, tmp.size(), hipMemcpyDeviceToHost));
+    for (int c = 0; c < e.C; ++c) for (int i = 0; i < e.n; ++i) for (int l = 0; l < e.nt; ++l)
+        f[(size_t)c * e.nt * e.n + l + (size_t)e.nt * i] = tmp[(size_t)c * e.nt * e.n + (size_t)l * e.n + i];
+    return 0;
+}
+int dqmc_init(dqmc_engine* h) { CHECK_E(h); DQ_HIP(hipSetDevice(h->e.device)); DQ_TRY(h->e.init()); return h->e.sync_and_check(); }
+int dqmc_get_G(dqmc_engine* h, double* G) {
+    CHECK_E(h); Engine& e = h->e; DQ_HIP(hipSetDevice(e.device)); DQ_TRY(e.sync_and_check());
+    DQ_HIP(hipMemcpy(G, e.G, sizeof(double) * e.C * e.nn, hipMemcpyDeviceToHost)); return 0;
+}
+int dqmc_set_G(dqmc_engine* h, const double* G) {
+    CHECK_E(h); Engine& e = h->e; DQ_HIP(hipSetDevice(e.device)); DQ_HIP(hipStreamSynchronize(e.s));
+    DQ_HIP(hipMemcpy(e.G, G, sizeof(double) * e.C * e.nn, hipMemcpyHostToDevice)); return 0;
+}
+int dqmc_get_logdet(dqmc_engine* h, double* ld) {
+    CHECK_E(h); Engine& e = h->e; DQ_HIP(hipSetDevice(e.device)); DQ_TRY(e.sync_and_check());
+    DQ_HIP(hipMemcpy(ld, e.logdet, sizeof(double) * e.C, hipMemcpyDeviceToHost)); return 0;
+}
+int dqmc_n_stack(dqmc_engine* h) { return h ? h->e.n_stack : 0; }
+int dqmc_get_stack(dqmc_engine* h, int i, double* L, double* d, double* R) {
+    CHECK_E(h); Engine& e = h->e; DQ_HIP(hipSetDevice(e.device));
+    if (i < 0 || i >= e.n_stack) { set_error("LDR Stack index out of bounds"); return DQMC_ERANGE; }
+    if (!e.stack_valid) { set_error("stack not initialised: call dqmc_init first"); return DQMC_EINVAL; }
+    DQ_TRY(e.sync_and_check());
+    LdrRef f = e.stk(i);
+    DQ_HIP(hipMemcpy(L, f.L.p, sizeof(double) * e.C * e.nn, hipMemcpyDeviceToHost));
+    DQ_HIP(hipMemcpy(R, f.R.p, sizeof(double) * e.C * e.nn, hipMemcpyDeviceToHost));
+    DQ_HIP(hipMemcpy(d, f.d.p, sizeof(double) * e.C * e.n, hipMemcpyDeviceToHost));
+    return 0;
+}
+int dqmc_sweep_0_to_beta(dqmc_engine* h, const int32_t* perm, const uint8_t* kprop, const double* u) {
+    CHECK_E(h); Engine& e = h->e; DQ_HIP(hipSetDevice(e.device));
+    if (!e.stack_valid) { set_error("dqmc_init must be called before sweeping"); return DQMC_EINVAL; }
+    DQ_TRY(e.upload_stream(perm, kprop, u)); return e.sweep_fwd();
+}
+int dqmc_sweep_beta_to_0(dqmc_engine* h, const int32_t* perm, const uint8_t* kprop, const double* u) {
+    CHECK_E(h); Engine& e = h->e; DQ_HIP(hipSetDevice(e.device));
+    if (!e.stack_valid) { set_error("dqmc_init must be called before sweeping"); return DQMC_EINVAL; }
+    DQ_TRY(e.upload_stream(perm, kprop, u)); return e.sweep_bwd();
+}
+int dqmc_sync(dqmc_engine* h) { CHECK_E(h); DQ_HIP(hipSetDevice(h->e.device)); return h->e.sync_and_check(); }
+int dqmc_get_stats(dqmc_engine* h, dqmc_stats* out) {
+    CHECK_E(h); Engine& e = h->e; DQ_HIP(hipSetDevice(e.device)); DQ_TRY(e.sync_and_check());
+    static_assert(sizeof(DevStats) == sizeof(dqmc_stats), "stats layout");
+    DQ_HIP(hipMemcpy(out, e.dstats, sizeof(DevStats) * e.C, hipMemcpyDeviceToHost)); return 0;
+}
+int dqmc_wrap_forward(dqmc_engine* h, int l) {
+    CHECK_E(h); Engine& e = h->e; DQ_HIP(hipSetDevice(e.device));
+    if (l < 0 || l >= e.nt) { set_error("time slice out of range"); return DQMC_ERANGE; }
+    return e.wrap_forward(l);
+}
+int dqmc_wrap_backward(dqmc_engine* h, int l) {
+    CHECK_E(h); Engine& e = h->e; DQ_HIP(hipSetDevice(e.device));
+    if (l < 0 || l >= e.nt) { set_error("time slice out of range"); return DQMC_ERANGE; }
+    return e.wrap_backward(l);
+}
+int dqmc_local_update_slice(dqmc_engine* h, int l, const int32_t* perm, const uint8_t* kprop, const double* u, int* accepted) {
+    CHECK_E(h); Engine& e = h->e; DQ_HIP(hipSetDevice(e.device));
+    if (l < 0 || l >= e.nt) { set_error("time slice out of range"); return DQMC_ERANGE; }
+    DQ_HIP(hipStreamSynchronize(e.s));
+    for (int c = 0; c < e.C; ++c) {
+        const size_t off = ((size_t)c * e.nt + l) * e.n;
+        DQ_HIP(hipMemcpy(e.rs_perm + off, perm + (size_t)c * e.n, sizeof(int32_t) * e.n, hipMemcpyHostToDevice));
+        DQ_HIP(hipMemcpy(e.rs_k + off, kprop + (size_t)c * e.n, e.n, hipMemcpyHostToDevice));
+        DQ_HIP(hipMemcpy(e.rs_u + off, u + (size_t)c * e.n, sizeof(double) * e.n, hipMemcpyHostToDevice));
+    }
+    DQ_TRY(e.local_update(l));
+    DQ_TRY(launch_fold_stats(e.dstats, e.acc + l, e.nt, 1, e.err, e.n_stack, 0, e.n, e.nt, e.C, e.s));
+    DQ_TRY(e.sync_and_check());
+    if (accepted) for (int c = 0; c < e.C; ++c) DQ_HIP(hipMemcpy(accepted + c, e.acc + (size_t)c * e.nt + l, sizeof(int), hipMemcpyDeviceToHost));
+    return 0;
+}
+int dqmc_calculate_Bbar(dqmc_engine* h, int is, double* out) {
+    CHECK_E(h); Engine& e = h->e; DQ_HIP(hipSetDevice(e.device));
+    if (is < 0 || is >= e.n_stack) { set_error("stack index out of range"); return DQMC_ERANGE; }
+    Mat bb; DQ_TRY(e.Bbar(is, &bb)); DQ_HIP(hipStreamSynchronize(e.s));
+    DQ_HIP(hipMemcpy(out, bb.p, sizeof(double) * e.C * e.nn, hipMemcpyDeviceToHost)); return 0;
+}
+// AttractiveHubbard::global_action (source/model.cpp:140-159); the field sums run on the host copy
+int dqmc_global_action(dqmc_engine* h, double* S) {
+    CHECK_E(h); Engine& e = h->e; DQ_HIP(hipSetDevice(e.device)); DQ_TRY(e.sync_and_check());
+    std::vector<int8_t> tmp((size_t)e.C * e.nt * e.n); std::vector<double> ld(e.C);
+    DQ_HIP(hipMemcpy(tmp.data(), e.fields, tmp.size(), hipMemcpyDeviceToHost));
+    DQ_HIP(hipMemcpy(ld.data(), e.logdet, sizeof(double) * e.C, hipMemcpyDeviceToHost));
+    const double alpha = -1.0;
+    for (int c = 0; c < e.C; ++c) {
+        double lb = 0.0, lg = 0.0;
+        for (int i = 0; i < e.n; ++i) for (int l = 0; l < e.nt; ++l) {     // arma::imat memory order
+            const int f = tmp[(size_t)c * e.nt * e.n + (size_t)l * e.n + i];
+            lb += alpha * e.g_host[c] * e.eta_host[f]; lg += std::log(e.gamma_host[f]);
+        }
+        S[c] = -2.0 * ld[c] - (lb + lg);
+    }
+    return 0;
+}
+int dqmc_update_kernel_time(dqmc_engine* h, double* ms, int64_t* n_launches, int64_t* n_accepted) {
+    CHECK_E(h); Engine& e = h->e; DQ_HIP(hipSetDevice(e.device)); DQ_TRY(e.sync_and_check());
+    std::vector<DevStats> st(e.C);
+    DQ_HIP(hipMemcpy(st.data(), e.dstats, sizeof(DevStats) * e.C, hipMemcpyDeviceToHost));
+    long long acc = 0; for (auto& x : st) acc += x.n_accepted;
+    if (ms) *ms = e.upd_ms; if (n_launches) *n_launches = e.upd_launches; if (n_accepted) *n_accepted = acc - e.upd_accept_base;
+    e.upd_ms = 0.0; e.upd_launches = 0; e.upd_accept_base = acc;
+    return 0;
+}
+int dqmc_set_profiling(dqmc_engine* h, int on) {
+    CHECK_E(h); Engine& e = h->e; DQ_HIP(hipSetDevice(e.device)); DQ_TRY(e.sync_and_check());
+    e.profiling = on != 0; return 0;
+}
+
+}  // extern "C"

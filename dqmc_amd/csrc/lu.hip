@@ -1,0 +1,194 @@
+// lu.hip -- the dense solves behind arma::solve / arma::log_det in
+// stablelinalg::inv_I_plus_ldr and inv_I_plus_ldr_mul_ldr
+// (source/stablelinalg.cpp:112,119-123,147,155), restated as LAPACK
+// dgetrf (partial pivoting) + dgetrs.
+//
+//   lu_kernel        one 1024-thread workgroup per chain, right-looking
+//                    elimination streaming the trailing matrix from L2: wave w
+//                    owns trailing columns k+1+w, +16, ...; lanes own rows, so
+//                    every access is 512-byte coalesced and the update needs no
+//                    reduction.  Emits the row permutation (perm[r] = source
+//                    row of row r of P*A) and sum log|u_kk|.
+//   lu_solve_kernel  P A = L U, solve A X = B for n right-hand sides.  Columns
+//                    of X are independent: grid = (n/16 column tiles) x chains,
+//                    each wave keeps 4 columns in registers (lanes <-> rows) and
+//                    runs the forward (unit L) and backward (U) substitutions
+//                    with the pivot element broadcast by a lane shuffle: no LDS,
+//                    no barriers.
+#include "common.h"
+
+namespace dq {
+
+template <int NR>
+__global__ __launch_bounds__(1024) void lu_kernel(Mat Am, int* perm_p, long perm_stride, double* logabsdet, int accumulate, int* info, int n) {
+    __shared__ double lvec[1024], urow[1024];
+    __shared__ double redv[16];
+    __shared__ int redi[16];
+    __shared__ int perm[1024];
+    __shared__ int s_bad;
+    const int chain = blockIdx.y;
+    double* __restrict__ A = Am.at(chain);
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (t < n) perm[t] = t;
+    if (t == 0) s_bad = 0;
+    double logsum = 0.0;      // thread 0 only
+    __syncthreads();
+
+    for (int k = 0; k < n; ++k) {
+        // (a) pivot search: first max of |A[k:, k]|
+        double best = -1.0; int bi = k;
+        if (t >= k && t < n) { best = fabs(A[t + (long)n * k]); bi = t; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double ob = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
+            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        if (lane == 0) { redv[wave] = best; redi[wave] = bi; }
+        __syncthreads();
+        best = redv[0]; bi = redi[0];
+#pragma unroll
+        for (int q = 1; q < 16; ++q) { const double ob = redv[q]; const int oi = redi[q]; if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; } }
+        const int p = bi;
+        // (b) swap rows k <-> p (thread t <-> column t), publish row k of U
+        if (t < n) {
+            double akc = A[k + (long)n * t];
+            if (p != k) { const double apc = A[p + (long)n * t]; A[p + (long)n * t] = akc; A[k + (long)n * t] = apc; akc = apc; }
+            urow[t] = akc;
+        }
+        if (t == 0) {
+            if (p != k) { const int tmp = perm[k]; perm[k] = perm[p]; perm[p] = tmp; }
+            if (!(best > 0.0)) s_bad = 1;
+            logsum += log(best);
+        }
+        __syncthreads();
+        // (c) multipliers
+        const double piv = urow[k];
+        if (t > k && t < n) { const double l = A[t + (long)n * k] / piv; A[t + (long)n * k] = l; lvec[t] = l; }
+        __syncthreads();
+        // (d) trailing update A[r,c] -= l_r u_c
+        double lr[NR];
+#pragma unroll
+        for (int q = 0; q < NR; ++q) { const int r = lane + 64 * q; lr[q] = (r > k && r < n) ? lvec[r] : 0.0; }
+        for (int c = k + 1 + wave; c < n; c += 16) {
+            const double uc = urow[c];
+#pragma unroll
+            for (int q = 0; q < NR; ++q) { const int r = lane + 64 * q; if (r > k && r < n) A[r + (long)n * c] -= lr[q] * uc; }
+        }
+        __syncthreads();
+    }
+    if (t < n) perm_p[(long)chain * perm_stride + t] = perm[t];
+    if (t == 0) {
+        if (logabsdet) logabsdet[chain] = (accumulate ? logabsdet[chain] : 0.0) + logsum;
+        if (info && s_bad) atomicOr(info, 1);
+    }
+}
+
+// mode 0: B = X on entry (dense RHS, overwritten by the solution)
+// mode 1: B = diag(dg) (X overwritten)
+template <int NR>
+__global__ __launch_bounds__(256) void lu_solve_kernel(CMat LUm, const int* perm_p, long perm_stride, Mat Xm, CVec dg, int mode, int n) {
+    constexpr int CW = 4;
+    const int chain = blockIdx.y;
+    const double* __restrict__ LU = LUm.at(chain);
+    const int* __restrict__ perm = perm_p + (long)chain * perm_stride;
+    double* __restrict__ X = Xm.at(chain);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c0 = blockIdx.x * 16 + wave * CW;
+    if (c0 >= n) return;
+    double x[CW][NR];
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+        const int r = lane + 64 * k;
+        const int src = (r < n) ? perm[r] : 0;
+#pragma unroll
+        for (int cc = 0; cc < CW; ++cc) {
+            const int c = c0 + cc;
+            double v = 0.0;
+            if (r < n && c < n) v = (mode == 1) ? (src == c ? dg.at(chain)[c] : 0.0) : X[src + (long)n * c];
+            x[cc][k] = v;
+        }
+    }
+    // forward substitution, unit lower L
+#pragma unroll
+    for (int q = 0; q < NR; ++q) {
+        for (int kk = 0; kk < 64; ++kk) {
+            const int k = 64 * q + kk;
+            if (k >= n) break;
+            double xk[CW];
+#pragma unroll
+            for (int cc = 0; cc < CW; ++cc) xk[cc] = __shfl(x[cc][q], kk, 64);
+#pragma unroll
+            for (int k2 = q; k2 < NR; ++k2) {
+                const int r = lane + 64 * k2;
+                if (r > k && r < n) {
+                    const double l = LU[r + (long)n * k];
+#pragma unroll
+                    for (int cc = 0; cc < CW; ++cc) x[cc][k2] -= l * xk[cc];
+                }
+            }
+        }
+    }
+    // backward substitution, U
+#pragma unroll
+    for (int q = NR - 1; q >= 0; --q) {
+        for (int kk = 63; kk >= 0; --kk) {
+            const int k = 64 * q + kk;
+            if (k >= n) continue;
+            const double ukk = LU[k + (long)n * k];
+            double xk[CW];
+#pragma unroll
+            for (int cc = 0; cc < CW; ++cc) {
+                const double v = __shfl(x[cc][q], kk, 64) / ukk;
+                xk[cc] = v;
+                if (lane == kk) x[cc][q] = v;
+            }
+#pragma unroll
+            for (int k2 = 0; k2 <= q; ++k2) {
+                const int r = lane + 64 * k2;
+                if (r < k) {
+                    const double u = LU[r + (long)n * k];
+#pragma unroll
+                    for (int cc = 0; cc < CW; ++cc) x[cc][k2] -= u * xk[cc];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int cc = 0; cc < CW; ++cc) {
+        if (c0 + cc >= n) continue;
+#pragma unroll
+        for (int k = 0; k < NR; ++k) { const int r = lane + 64 * k; if (r < n) X[r + (long)n * (c0 + cc)] = x[cc][k]; }
+    }
+}
+
+template <int NR>
+static int launch_lu_nr(Mat A, int* perm, long ps, double* lad, int acc, int* info, int n, int n_chains, hipStream_t s) {
+    hipLaunchKernelGGL((lu_kernel<NR>), dim3(1, n_chains), dim3(1024), 0, s, A, perm, ps, lad, acc, info, n);
+    DQ_HIP(hipGetLastError());
+    return 0;
+}
+int launch_lu(Mat A, int* perm, long perm_stride, double* logabsdet, int accumulate_logdet, int* info, int n, int n_chains, hipStream_t s) {
+    if (n > 1024) { set_error("LU kernel supports n <= 1024"); return -1; }
+    if (n <= 64) return launch_lu_nr<1>(A, perm, perm_stride, logabsdet, accumulate_logdet, info, n, n_chains, s);
+    if (n <= 128) return launch_lu_nr<2>(A, perm, perm_stride, logabsdet, accumulate_logdet, info, n, n_chains, s);
+    if (n <= 256) return launch_lu_nr<4>(A, perm, perm_stride, logabsdet, accumulate_logdet, info, n, n_chains, s);
+    if (n <= 576) return launch_lu_nr<9>(A, perm, perm_stride, logabsdet, accumulate_logdet, info, n, n_chains, s);
+    return launch_lu_nr<16>(A, perm, perm_stride, logabsdet, accumulate_logdet, info, n, n_chains, s);
+}
+
+template <int NR>
+static int launch_solve_nr(CMat LU, const int* perm, long ps, Mat X, CVec dg, int mode, int n, int n_chains, hipStream_t s) {
+    hipLaunchKernelGGL((lu_solve_kernel<NR>), dim3((n + 15) / 16, n_chains), dim3(256), 0, s, LU, perm, ps, X, dg, mode, n);
+    DQ_HIP(hipGetLastError());
+    return 0;
+}
+int launch_lu_solve(CMat LU, const int* perm, long perm_stride, Mat X, CVec dg, int mode, int n, int n_chains, hipStream_t s) {
+    if (n > 1024) { set_error("LU solve kernel supports n <= 1024"); return -1; }
+    if (n <= 64) return launch_solve_nr<1>(LU, perm, perm_stride, X, dg, mode, n, n_chains, s);
+    if (n <= 128) return launch_solve_nr<2>(LU, perm, perm_stride, X, dg, mode, n, n_chains, s);
+    if (n <= 256) return launch_solve_nr<4>(LU, perm, perm_stride, X, dg, mode, n, n_chains, s);
+    if (n <= 576) return launch_solve_nr<9>(LU, perm, perm_stride, X, dg, mode, n, n_chains, s);
+    return launch_solve_nr<16>(LU, perm, perm_stride, X, dg, mode, n, n_chains, s);
+}
+
+}  // namespace dq

@@ -71,8 +71,9 @@ class HubbardModel:
         self.invexpK = np.asfortranarray(expm_sym(self.dtau * self.K))
         self.n_stack = -(-self.nt // self.n_stab)
 
-    def engine(self, lib, device: int = 0):
-        return lib.engine(self.n, self.nt, self.n_stab, self.g, self.gamma, self.eta, self.expK, self.invexpK, device=device)
+    def engine(self, lib, device: int = 0, n_chains=None):
+        return lib.engine(self.n, self.nt, self.n_stab, self.g, self.gamma, self.eta, self.expK, self.invexpK,
+                          device=device, n_chains=n_chains)
 
     def random_fields(self, seed: int) -> np.ndarray:
         """i.i.d. uniform {0,1,2,3} fields, shape (nt, n) (include/field.h:54-57)."""

@@ -130,6 +130,17 @@ int dqmc_rank1_update(int n, double* G, int i, double delta);
 int dqmc_create(dqmc_engine** out, int device, int n_sites, int nt, int n_stab,
                 double g, const double gamma[4], const double eta[4],
                 const double* expK, const double* invexpK);
+/* Batched form: one engine advancing n_chains independent Markov chains (the
+ * reference's MPI ranks, source/main.cpp:20-37) on one GPU; every kernel launch
+ * covers all chains.  g, expK, invexpK carry a leading n_chains dimension (each
+ * chain may have its own beta, as under parallel tempering, source/main.cpp:47-67).
+ * For an engine with n_chains > 1 EVERY per-chain array of the calls below
+ * (fields, G, logdet, stack L/d/R, perm/kprop/u, stats, accepted, Bbar, S)
+ * gains a leading n_chains dimension; dqmc_create is the n_chains = 1 case.   */
+int dqmc_create_batch(dqmc_engine** out, int device, int n_chains, int n_sites, int nt, int n_stab,
+                      const double* g, const double gamma[4], const double eta[4],
+                      const double* expK, const double* invexpK);
+int dqmc_n_chains(dqmc_engine* e);
 void dqmc_destroy(dqmc_engine* e);
 
 /* GHQField::set_fields / fields() (include/field.h:64,72-74).                */

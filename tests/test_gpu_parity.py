@@ -1,0 +1,263 @@
+"""GPU parity tests (-m gpu): the HIP library, called through the C ABI,
+against the CPU oracle on identical inputs.
+
+Tolerance (BASELINE.json north_star: "Green's function within 1e-10 of the
+CPU reference"): fp64 everywhere; |dG| <= 1e-10 absolute on thermalised
+fields, <= 1e-10 * max|G| on i.i.d. random fields (two fp64
+evaluations with different summation order already differ by 4e-8 absolute
+at cfg 3 on random fields where max|G| ~ 1e3).  Integer results (fields,
+accepted counts) must match exactly.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from dqmc_amd import CONFIGS, HubbardModel
+from oracle.numpy_ref import free_fermion_G
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+TOL = 1e-10
+
+
+def ldr_mat(F):
+    L, d, R = F
+    return (L * d[None, :]) @ R
+
+
+def close(a, b, tol=TOL):
+    a = np.asarray(a); b = np.asarray(b)
+    return np.abs(a - b).max() <= tol * max(1.0, np.abs(b).max())
+
+
+def graded(rng, n, lo=-6, hi=6):
+    return rng.standard_normal((n, n)) * np.exp(rng.uniform(lo, hi, n))[None, :]
+
+
+@pytest.mark.parametrize("n", [4, 16, 36, 64, 100, 256])
+def test_gemm(hip, n):
+    rng = np.random.default_rng(n)
+    A = rng.standard_normal((n, n)); B = rng.standard_normal((n, n))      # asymmetric on purpose
+    assert close(hip.gemm(A, B), A @ B, 1e-13 * n)
+    assert close(hip.gemm(A, B, transA=True), A.T @ B, 1e-13 * n)
+    assert close(hip.gemm(A, B, transB=True), A @ B.T, 1e-13 * n)
+    assert close(hip.gemm(np.eye(n), B), B, 1e-15)
+
+
+@pytest.mark.parametrize("n", [4, 16, 36, 64, 100, 256])
+def test_to_ldr(hip, orc, n):
+    rng = np.random.default_rng(100 + n)
+    M = graded(rng, n)
+    L, d, R = hip.to_ldr(M)
+    Lo, do, Ro = orc.to_ldr(M)
+    assert np.abs(L.T @ L - np.eye(n)).max() < 1e-13 * n
+    assert np.abs(ldr_mat((L, d, R)) - M).max() < 1e-13 * n * np.abs(M).max()
+    assert np.allclose(d, do, rtol=1e-10)                  # same pivot order, same |diag R0|
+    assert np.all(np.diff(d) <= 1e-12 * d[:-1])            # non-increasing (true column pivoting)
+    assert close(R, Ro, 1e-9) and close(np.abs(L), np.abs(Lo), 1e-9)
+
+
+@pytest.mark.parametrize("n", [16, 64, 256])
+def test_ldr_products_and_inverses(hip, orc, n):
+    rng = np.random.default_rng(200 + n)
+    M1 = graded(rng, n); M2 = graded(rng, n).T
+    F1 = orc.to_ldr(M1); F2 = orc.to_ldr(M2)
+    for got, ref in [(hip.ldr_mul_mat(F1, M2), orc.ldr_mul_mat(F1, M2)),
+                     (hip.mat_mul_ldr(M2, F1), orc.mat_mul_ldr(M2, F1)),
+                     (hip.ldr_mul_ldr(F1, F2), orc.ldr_mul_ldr(F1, F2))]:
+        ref_m = ldr_mat(ref)
+        assert np.abs(ldr_mat(got) - ref_m).max() < 1e-11 * np.abs(ref_m).max()
+        assert np.allclose(got[1], ref[1], rtol=1e-9)
+    G, ld = hip.inv_I_plus_ldr(F1); Go, ldo = orc.inv_I_plus_ldr(F1)
+    assert close(G, Go) and abs(ld - ldo) < 1e-9 * max(1.0, abs(ldo))
+    G2 = hip.inv_I_plus_ldr_mul_ldr(F1, F2); G2o = orc.inv_I_plus_ldr_mul_ldr(F1, F2)
+    assert close(G2, G2o, 1e-9)
+
+
+def test_rank1_update(hip, orc):
+    rng = np.random.default_rng(5)
+    for n in (16, 64, 256):
+        G = rng.standard_normal((n, n)); i = int(rng.integers(n)); delta = 0.7
+        assert close(hip.rank1_update(G, i, delta), orc.rank1_update(G, i, delta), 1e-13)
+
+
+@pytest.mark.parametrize("L,beta,nt", [(4, 2.0, 20), (8, 4.0, 80), (16, 8.0, 200)])
+def test_free_fermions_known_answer(hip, L, beta, nt):
+    m = HubbardModel(L1=L, L2=L, U=0.0, beta=beta, nt=nt)
+    e = m.engine(hip); e.set_fields(m.random_fields(3)); e.init()
+    G, ld = free_fermion_G(m)
+    assert np.abs(e.get_G() - G).max() < 1e-12
+    assert abs(e.get_logdet() - ld) < 1e-9 * max(1.0, abs(ld))
+
+
+@pytest.mark.parametrize("cfg", ["cfg1", "cfg2", "cfg3"])
+def test_init_parity(hip, orc, cfg):
+    m = HubbardModel(**CONFIGS[cfg]); f = m.random_fields(7)
+    e = m.engine(hip); e.set_fields(f); e.init()
+    o = m.engine(orc); o.set_fields(f); o.init()
+    assert (e.get_fields() == f).all()
+    Go = o.get_G()
+    err = np.abs(e.get_G() - Go).max()
+    print(f"{cfg}: init max|dG| = {err:.3e}, max|G| = {np.abs(Go).max():.3e}")
+    assert err <= TOL * max(1.0, np.abs(Go).max())
+    assert abs(e.get_logdet() - o.get_logdet()) < 1e-9 * max(1.0, abs(o.get_logdet()))
+    for i in range(e.n_stack()):
+        a, b = ldr_mat(e.get_stack(i)), ldr_mat(o.get_stack(i))
+        assert np.abs(a - b).max() < 1e-9 * np.abs(b).max()
+    assert close(e.calculate_Bbar(0), o.calculate_Bbar(0), 1e-13)
+    assert abs(e.global_action() - o.global_action()) < 1e-8 * abs(o.global_action())
+
+
+def test_wrap_and_slice_update(hip, orc):
+    m = HubbardModel(**CONFIGS["cfg2"]); f = m.random_fields(9)
+    e = m.engine(hip); e.set_fields(f); e.init()
+    o = m.engine(orc); o.set_fields(f); o.init()
+    rng = np.random.default_rng(1)
+    for l in (0, 1, 2):
+        e.wrap_forward(l); o.wrap_forward(l)
+        assert close(e.get_G(), o.get_G())
+        s = m.random_stream(rng, 1)
+        assert e.local_update_slice(l, *s) == o.local_update_slice(l, *s)
+        assert (e.get_fields() == o.get_fields()).all()
+        assert close(e.get_G(), o.get_G())
+    for l in (2, 1):
+        s = m.random_stream(rng, 1)
+        assert e.local_update_slice(l, *s) == o.local_update_slice(l, *s)
+        e.wrap_backward(l); o.wrap_backward(l)
+        assert close(e.get_G(), o.get_G())
+    # edge cases: every proposal rejected / every proposal accepted
+    perm, k, u = m.random_stream(rng, 1)
+    assert e.local_update_slice(5, perm, k, np.ones_like(u)) == 0
+    acc = e.local_update_slice(5, perm, k, np.full_like(u, -1.0)); o.local_update_slice(5, perm, k, np.ones_like(u))
+    assert acc == m.n == o.local_update_slice(5, perm, k, np.full_like(u, -1.0))
+    assert (e.get_fields() == o.get_fields()).all() and close(e.get_G(), o.get_G(), 1e-9)
+
+
+@pytest.mark.parametrize("cfg,n_sweeps", [("cfg1", 3), ("cfg2", 3)])
+def test_sweep_parity(hip, orc, cfg, n_sweeps):
+    m = HubbardModel(**CONFIGS[cfg]); f = m.random_fields(7)
+    e = m.engine(hip); e.set_fields(f); e.init()
+    o = m.engine(orc); o.set_fields(f); o.init()
+    rng = np.random.default_rng(3)
+    for sw in range(n_sweeps):
+        s1, s2 = m.random_stream(rng), m.random_stream(rng)
+        e.sweep_0_to_beta(*s1); o.sweep_0_to_beta(*s1)
+        assert (e.get_fields() == o.get_fields()).all(), f"fields diverged in forward sweep {sw}"
+        assert close(e.get_G(), o.get_G())
+        e.sweep_beta_to_0(*s2); o.sweep_beta_to_0(*s2)
+        assert (e.get_fields() == o.get_fields()).all(), f"fields diverged in backward sweep {sw}"
+        err = np.abs(e.get_G() - o.get_G()).max()
+        print(f"{cfg} sweep {sw}: max|dG| = {err:.3e} max|G| = {np.abs(o.get_G()).max():.3e}")
+        assert err <= TOL * max(1.0, np.abs(o.get_G()).max())
+    se, so = e.stats(), o.stats()
+    assert se.n_accepted == so.n_accepted and se.n_proposed == so.n_proposed
+    assert abs(se.acc_rate - so.acc_rate) < 1e-12 and se.n_err == so.n_err
+    assert se.max_err < 10 * so.max_err + 1e-12
+    assert abs(e.get_logdet() - o.get_logdet()) < 1e-9 * max(1.0, abs(o.get_logdet()))
+
+
+def test_short_last_block(hip, orc):
+    m = HubbardModel(L1=4, L2=4, U=4.0, beta=2.3, nt=23, n_stab=10); f = m.random_fields(2)
+    e = m.engine(hip); e.set_fields(f); e.init(); o = m.engine(orc); o.set_fields(f); o.init()
+    rng = np.random.default_rng(1); s1, s2 = m.random_stream(rng), m.random_stream(rng)
+    e.sweep_0_to_beta(*s1); e.sweep_beta_to_0(*s2); o.sweep_0_to_beta(*s1); o.sweep_beta_to_0(*s2)
+    assert (e.get_fields() == o.get_fields()).all() and close(e.get_G(), o.get_G())
+
+
+def test_non_multiple_of_16_lattice(hip, orc):
+    # the reference's own example is 6x6 (examples/parameters.in): n = 36
+    m = HubbardModel(L1=6, L2=6, U=4.0, beta=4.0, nt=40, n_stab=10); f = m.random_fields(4)
+    e = m.engine(hip); e.set_fields(f); e.init(); o = m.engine(orc); o.set_fields(f); o.init()
+    assert close(e.get_G(), o.get_G())
+    rng = np.random.default_rng(2); s1, s2 = m.random_stream(rng), m.random_stream(rng)
+    e.sweep_0_to_beta(*s1); e.sweep_beta_to_0(*s2); o.sweep_0_to_beta(*s1); o.sweep_beta_to_0(*s2)
+    assert (e.get_fields() == o.get_fields()).all() and close(e.get_G(), o.get_G())
+
+
+def test_cfg3_one_block_then_properties(hip, orc):
+    """Headline size (16x16, U=8, beta=8, nt=200).  The oracle runs one
+    stabilisation block (10 slices) for direct parity; the full sweep is
+    checked through size-independent properties."""
+    m = HubbardModel(**CONFIGS["cfg3"]); f = m.random_fields(12)
+    e = m.engine(hip); e.set_fields(f); e.init(); o = m.engine(orc); o.set_fields(f); o.init()
+    G0 = o.get_G(); scale = np.abs(G0).max()
+    assert np.abs(e.get_G() - G0).max() <= TOL * scale
+    rng = np.random.default_rng(4)
+    for l in range(10):
+        s = m.random_stream(rng, 1)
+        e.wrap_forward(l); o.wrap_forward(l)
+        assert e.local_update_slice(l, *s) == o.local_update_slice(l, *s)
+    assert (e.get_fields() == o.get_fields()).all()
+    assert np.abs(e.get_G() - o.get_G()).max() <= 1e-9 * max(1.0, np.abs(o.get_G()).max())
+    # full sweep with every proposal rejected: G(beta,beta) = G(0,0), fields untouched,
+    # wrap-vs-stabilised error below the reference's alarm threshold (source/dqmc.cpp:390)
+    e2 = m.engine(hip); e2.set_fields(f); e2.init()
+    perm, k, u = m.random_stream(rng); u[:] = 1.0
+    e2.sweep_0_to_beta(perm, k, u)
+    assert np.abs(e2.get_G() - G0).max() <= 1e-9 * scale
+    e2.sweep_beta_to_0(perm, k, u)
+    assert np.abs(e2.get_G() - G0).max() <= 1e-9 * scale
+    st = e2.stats()
+    assert st.n_accepted == 0 and st.n_err == 2 * m.n_stack and st.max_err < 1e-5 * scale
+    assert (e2.get_fields() == f).all()
+    # a real sweep keeps G consistent with a from-scratch evaluation of the final fields
+    e3 = m.engine(hip); e3.set_fields(f); e3.init()
+    s1, s2 = m.random_stream(rng), m.random_stream(rng)
+    e3.sweep_0_to_beta(*s1); e3.sweep_beta_to_0(*s2)
+    f3 = e3.get_fields(); G3 = e3.get_G(); st3 = e3.stats()
+    assert 0.2 < st3.n_accepted / st3.n_proposed < 0.8
+    e4 = m.engine(hip); e4.set_fields(f3); e4.init()
+    assert np.abs(G3 - e4.get_G()).max() <= 1e-8 * max(1.0, np.abs(G3).max())
+
+
+def test_batched_engine(hip, orc):
+    m = HubbardModel(**CONFIGS["cfg2"]); C = 3
+    f = np.stack([m.random_fields(20 + c) for c in range(C)])
+    e = m.engine(hip, n_chains=C); e.set_fields(f); e.init()
+    os_ = []
+    for c in range(C):
+        o = m.engine(orc); o.set_fields(f[c]); o.init(); os_.append(o)
+    G = e.get_G()
+    for c in range(C):
+        assert close(G[c], os_[c].get_G())
+    rng = np.random.default_rng(8)
+    streams = [m.random_stream(rng) for _ in range(C)]
+    s = tuple(np.stack([st[k] for st in streams]) for k in range(3))
+    e.sweep_0_to_beta(*s)
+    G = e.get_G(); fe = e.get_fields(); st = e.stats()
+    for c in range(C):
+        os_[c].sweep_0_to_beta(*streams[c])
+        assert (fe[c] == os_[c].get_fields()).all() and close(G[c], os_[c].get_G())
+        assert st[c].n_accepted == os_[c].stats().n_accepted
+
+
+def test_error_codes(hip):
+    from dqmc_amd import DqmcError
+    m = HubbardModel(**CONFIGS["cfg1"]); e = m.engine(hip); e.set_fields(m.random_fields(1))
+    with pytest.raises(DqmcError):
+        e.get_stack(0)                       # before init
+    e.init()
+    with pytest.raises(DqmcError) as ei:
+        e.get_stack(e.n_stack())             # LDRStack out_of_range (include/stackngf.h:61)
+    assert ei.value.code == -4
+    with pytest.raises(DqmcError):
+        e.wrap_forward(-1)
+    bad = m.random_fields(1); bad[0, 0] = 7
+    with pytest.raises(DqmcError):
+        e.set_fields(bad)
+
+
+@pytest.mark.parametrize("name", sorted(fn[:-4] for fn in os.listdir(GOLD) if fn.endswith(".npz")) if os.path.isdir(GOLD) else [])
+def test_golden_vectors(hip, name):
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    m = HubbardModel(L1=int(z["L1"]), L2=int(z["L2"]), U=float(z["U"]), beta=float(z["beta"]), nt=int(z["nt"]), n_stab=int(z["n_stab"]))
+    e = m.engine(hip); e.set_fields(z["fields"]); e.init()
+    err = np.abs(e.get_G() - z["G0"]).max(); scale = max(1.0, np.abs(z["G0"]).max())
+    print(f"{name}: max|dG| = {err:.3e} (max|G| = {scale:.3e}, tol {float(z['tol']):.0e})")
+    assert err <= float(z["tol"]) * scale
+    assert abs(e.get_logdet() - float(z["logdet"])) < 1e-8 * max(1.0, abs(float(z["logdet"])))
+    if "G_after" in z.files:
+        e.sweep_0_to_beta(z["perm_f"], z["k_f"], z["u_f"]); e.sweep_beta_to_0(z["perm_b"], z["k_b"], z["u_b"])
+        assert (e.get_fields() == z["fields_after"]).all()
+        assert np.abs(e.get_G() - z["G_after"]).max() <= float(z["tol"]) * max(1.0, np.abs(z["G_after"]).max())

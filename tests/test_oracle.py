@@ -1,0 +1,138 @@
+"""CPU tests: the oracle against analytic answers, the independent numpy/scipy
+evaluation, its LAPACK back end and the committed golden vectors.  The
+reference ships no tests or fixtures, so these are what
+pins the oracle ("parity unpinned" by the reference itself)."""
+import os
+
+import numpy as np
+import pytest
+
+from dqmc_amd import CONFIGS, HubbardModel
+from oracle.numpy_ref import NumpyChain, free_fermion_G
+import oracle.numpy_ref as nr
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _ldr_to_mat(F):
+    L, d, R = F
+    return (L * d[None, :]) @ R
+
+
+@pytest.mark.parametrize("L,beta,nt", [(4, 2.0, 20), (6, 4.0, 40), (8, 4.0, 80)])
+def test_free_fermions_known_answer(orc, L, beta, nt):
+    # U = 0 => B_l = exp(-dtau K) for any field => G(0,0) = (I + exp(-beta K))^-1 analytically
+    m = HubbardModel(L1=L, L2=L, U=0.0, beta=beta, nt=nt)
+    e = m.engine(orc); e.set_fields(m.random_fields(3)); e.init()
+    G, ld = free_fermion_G(m)
+    assert np.abs(e.get_G() - G).max() < 1e-13
+    assert abs(e.get_logdet() - ld) < 1e-10
+
+
+@pytest.mark.parametrize("n", [16, 36, 64])
+def test_ldr_algebra_vs_numpy(orc, n):
+    rng = np.random.default_rng(n)
+    M1 = rng.standard_normal((n, n)) * np.exp(rng.uniform(-6, 6, n))[None, :]
+    M2 = rng.standard_normal((n, n)) * np.exp(rng.uniform(-6, 6, n))[:, None]
+    F1 = orc.to_ldr(M1); F1n = nr.to_ldr(M1)
+    assert np.allclose(_ldr_to_mat(F1), M1, rtol=1e-12, atol=1e-12 * np.abs(M1).max())
+    assert np.allclose(F1[1], F1n[1], rtol=1e-11)                       # d (pivot order identical)
+    assert np.abs(F1[0].T @ F1[0] - np.eye(n)).max() < 1e-13            # L orthogonal
+    F2 = orc.to_ldr(M2)
+    for got, ref, exact in [(orc.ldr_mul_mat(F1, M2), nr.ldr_mul_mat(F1, M2), M1 @ M2),
+                            (orc.mat_mul_ldr(M2, F1), nr.mat_mul_ldr(M2, F1), M2 @ M1),
+                            (orc.ldr_mul_ldr(F1, F2), nr.ldr_mul_ldr(F1, F2), M1 @ M2)]:
+        scale = np.abs(exact).max()
+        assert np.abs(_ldr_to_mat(got) - exact).max() < 1e-11 * scale
+        assert np.abs(_ldr_to_mat(got) - _ldr_to_mat(ref)).max() < 1e-11 * scale
+    G, ld = orc.inv_I_plus_ldr(F1); Gn, ldn = nr.inv_I_plus_ldr(F1)
+    assert np.abs(G - Gn).max() < 1e-10 * max(1.0, np.abs(Gn).max()) and abs(ld - ldn) < 1e-9
+    G2 = orc.inv_I_plus_ldr_mul_ldr(F1, F2); G2n = nr.inv_I_plus_ldr_mul_ldr(F1, F2)
+    assert np.abs(G2 - G2n).max() < 1e-9 * max(1.0, np.abs(G2n).max())
+
+
+@pytest.mark.parametrize("cfg", ["cfg1", "cfg2"])
+def test_sweep_vs_numpy_chain(orc, cfg):
+    m = HubbardModel(**CONFIGS[cfg]); f = m.random_fields(7)
+    e = m.engine(orc); e.set_fields(f); e.init()
+    c = NumpyChain(m, f); c.init()
+    assert np.abs(e.get_G() - c.G).max() < 1e-11 and abs(e.get_logdet() - c.logdet) < 1e-10
+    rng = np.random.default_rng(3)
+    for _ in range(2):
+        s1, s2 = m.random_stream(rng), m.random_stream(rng)
+        e.sweep_0_to_beta(*s1); e.sweep_beta_to_0(*s2)
+        c.sweep_fwd(*s1); c.sweep_bwd(*s2)
+        assert (e.get_fields() == c.f).all()
+        assert np.abs(e.get_G() - c.G).max() < 1e-11
+    st = e.stats()
+    assert st.n_accepted == c.n_acc and st.n_proposed == 4 * m.nt * m.n
+    assert abs(st.max_err - max(c.errs)) < 0.5 * max(c.errs) + 1e-12
+    assert abs(e.global_action() - c.global_action()) < 1e-8
+
+
+def test_lapack_backend_agrees(orc):
+    if not orc.set_backend("lapack"):
+        pytest.skip("no LAPACK library on this host")
+    try:
+        m = HubbardModel(**CONFIGS["cfg2"]); f = m.random_fields(11)
+        e = m.engine(orc); e.set_fields(f); e.init(); Gl = e.get_G(); ldl = e.get_logdet()
+    finally:
+        orc.set_backend("builtin")
+    e2 = m.engine(orc); e2.set_fields(f); e2.init()
+    assert np.abs(Gl - e2.get_G()).max() < 1e-11 and abs(ldl - e2.get_logdet()) < 1e-10
+
+
+def test_identities(orc):
+    # SM vs recompute, ratio vs delta-logdet, G(beta,beta)=G(0,0)
+    m = HubbardModel(**CONFIGS["cfg2"]); f = m.random_fields(5)
+    e = m.engine(orc); e.set_fields(f); e.init(); G0 = e.get_G(); ld0 = e.get_logdet()
+    # one flip at slice 0 site i: update acts on Gtt[1] = B_0 G B_0^-1
+    e.wrap_forward(0); G1 = e.get_G()
+    i = 5; old = int(f[0, i]); new = (old + 1) % 4
+    delta = np.exp(m.g * (m.eta[new] - m.eta[old])) - 1.0
+    Gsm = orc.rank1_update(G1, i, delta)
+    f2 = f.copy(); f2[0, i] = new
+    e2 = m.engine(orc); e2.set_fields(f2); e2.init(); e2.wrap_forward(0)
+    assert np.abs(Gsm - e2.get_G()).max() < 1e-9 * max(1.0, np.abs(Gsm).max())
+    assert abs(np.log(abs(1.0 + (1.0 - G1[i, i]) * delta)) - (e2.get_logdet() - ld0)) < 1e-9
+    # a full forward pass with every proposal rejected (u = 1) returns to G(0,0)
+    rng = np.random.default_rng(0); perm, k, u = m.random_stream(rng); u[:] = 1.0
+    e.set_G(G0); e.sweep_0_to_beta(perm, k, u)
+    assert np.abs(e.get_G() - G0).max() < 1e-9 * max(1.0, np.abs(G0).max())
+    assert e.stats().n_accepted == 0 and e.stats().max_err < 1e-6
+
+
+def test_stack_index_errors(orc):
+    from dqmc_amd import DqmcError
+    m = HubbardModel(**CONFIGS["cfg1"]); e = m.engine(orc); e.set_fields(m.random_fields(1)); e.init()
+    assert e.n_stack() == 2
+    with pytest.raises(DqmcError):
+        e.get_stack(2)                      # LDRStack::operator[] std::out_of_range (include/stackngf.h:61)
+    with pytest.raises(DqmcError):
+        e.wrap_forward(m.nt)
+
+
+def test_short_last_block(orc):
+    # nt % n_stab != 0 (source/dqmc.cpp:13-18)
+    m = HubbardModel(L1=4, L2=4, U=4.0, beta=2.3, nt=23, n_stab=10); f = m.random_fields(2)
+    e = m.engine(orc); e.set_fields(f); e.init(); c = NumpyChain(m, f); c.init()
+    assert e.n_stack() == 3
+    rng = np.random.default_rng(1); s1, s2 = m.random_stream(rng), m.random_stream(rng)
+    e.sweep_0_to_beta(*s1); e.sweep_beta_to_0(*s2); c.sweep_fwd(*s1); c.sweep_bwd(*s2)
+    assert (e.get_fields() == c.f).all() and np.abs(e.get_G() - c.G).max() < 1e-10
+
+
+@pytest.mark.parametrize("name", sorted(fn[:-4] for fn in os.listdir(GOLD) if fn.endswith(".npz")) if os.path.isdir(GOLD) else [])
+def test_golden_vectors(orc, name):
+    """Committed fixtures (tests/golden/make_golden.py): inputs + outputs of the
+    numpy/scipy evaluation; the oracle must reproduce them."""
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    m = HubbardModel(L1=int(z["L1"]), L2=int(z["L2"]), U=float(z["U"]), beta=float(z["beta"]), nt=int(z["nt"]), n_stab=int(z["n_stab"]))
+    e = m.engine(orc); e.set_fields(z["fields"]); e.init()
+    scale = max(1.0, np.abs(z["G0"]).max())
+    assert np.abs(e.get_G() - z["G0"]).max() < float(z["tol"]) * scale
+    assert abs(e.get_logdet() - float(z["logdet"])) < 1e-8 * max(1.0, abs(float(z["logdet"])))
+    if "G_after" in z.files:
+        e.sweep_0_to_beta(z["perm_f"], z["k_f"], z["u_f"]); e.sweep_beta_to_0(z["perm_b"], z["k_b"], z["u_b"])
+        assert (e.get_fields() == z["fields_after"]).all()
+        assert np.abs(e.get_G() - z["G_after"]).max() < float(z["tol"]) * max(1.0, np.abs(z["G_after"]).max())
