@@ -1,0 +1,159 @@
+#!/usr/bin/env python3
+"""bench.py -- MC sweeps/s of the equal-time DQMC sweep on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one Monte Carlo sweep (sweep_0_to_beta + sweep_beta_to_0 =
+2*Ltau*N single-site proposals, source/main.cpp:156-157) of every Markov chain
+this rank owns.  Workload: BASELINE.json configs[2], 16x16 Hubbard, U=8,
+beta=8, Ltau=200, n_stab=10 -- one chain per GPU by default (the named
+config); --chains-per-gpu C batches C independent chains into every kernel
+launch.  Inputs are synthetic and resident in HBM before the timed region
+(only the per-sweep random stream, 2.6 MB/chain, is uploaded asynchronously).
+
+For N > 1 the driver launches one rank per GPU with torch.distributed.run;
+chains never communicate during sweeps (source/main.cpp:128-171), so there is
+no data-path collective: scaling is weak, value = total sweeps / max time.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s achievable)
+FP64_MFMA_PEAK_TFLOPS = 78.6  # 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz (AMD MI355X spec)
+
+
+def gen_streams(model, rng, C):
+    st = [model.random_stream(rng) for _ in range(C)]
+    return tuple(np.stack([s[k] for s in st]) for k in range(3))
+
+
+def cpu_baseline(model, seed, budget_s=20.0):
+    """The oracle (a port: the reference cannot be built here) timed on one host
+    core on a bounded sample of the same workload."""
+    from oracle import oracle
+    orc = oracle()
+    kind_blas = "lapack" if orc.set_backend("lapack") else "builtin"
+    try:
+        e = model.engine(orc); e.set_fields(model.random_fields(seed)); e.init()
+        rng = np.random.default_rng(seed)
+        e.sweep_0_to_beta(*model.random_stream(rng)); e.sweep_beta_to_0(*model.random_stream(rng))   # warm-up sweep
+        n = 0; t0 = time.perf_counter()
+        while True:
+            e.sweep_0_to_beta(*model.random_stream(rng)); e.sweep_beta_to_0(*model.random_stream(rng)); n += 1
+            dt = time.perf_counter() - t0
+            if dt > budget_s or n >= 50:
+                break
+        backend = orc.backend()
+    finally:
+        orc.set_backend("builtin")
+    return {"value": n / dt, "unit": "sweeps/s", "cores": 1, "kind": "port",
+            "sample": f"{n} sweeps of 1 chain after 1 warm-up sweep, single thread, {backend}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="cfg3")
+    ap.add_argument("--chains-per-gpu", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=20.0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # "nccl" is RCCL on ROCm
+    elif torch.cuda.is_available():
+        torch.cuda.set_device(local_rank)
+
+    import dqmc_amd
+    lib = dqmc_amd.lib()
+    if lib.device_count() == 0:
+        raise SystemExit("bench.py needs a GPU: the HIP library has no CPU fallback")
+    model = dqmc_amd.HubbardModel(**dqmc_amd.CONFIGS[args.config])
+    C = args.chains_per_gpu
+    eng = model.engine(lib, device=local_rank, n_chains=C)
+    fields = np.stack([model.random_fields(12345 + rank * C + c) for c in range(C)])
+    eng.set_fields(fields); eng.init()
+    rng = np.random.default_rng(777 + rank)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def sweep():
+        eng.sweep_0_to_beta(*gen_streams(model, rng, C))
+        eng.sweep_beta_to_0(*gen_streams(model, rng, C))
+
+    for _ in range(args.warmup):
+        sweep()
+    eng.sync()
+    st0 = eng.stats()
+    eng.set_profiling(True); eng.update_kernel_time()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sweep()
+    eng.sync()
+    barrier()
+    dt = time.perf_counter() - t0
+    upd_ms, upd_launches, upd_acc = eng.update_kernel_time()
+    eng.set_profiling(False)
+    st1 = eng.stats()
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda"); dist.all_reduce(tt, op=dist.ReduceOp.MAX); dt = float(tt.item())
+
+    if rank == 0:
+        n = model.n
+        total_sweeps = world * C * args.steps
+        s0 = st0[0] if C > 1 or isinstance(st0, list) else st0
+        s1 = st1[0] if C > 1 or isinstance(st1, list) else st1
+        acc_rate = (s1.n_accepted - s0.n_accepted) / max(1, s1.n_proposed - s0.n_proposed)
+        # rank-1 update roofline: 16*N^2 algorithmic bytes per ACCEPTED proposal (read + write G once,
+        # SURVEY.md 8d); one launch = the local update of one time slice (all chains of this rank)
+        bytes_per_launch = 16.0 * n * n * upd_acc / max(1, upd_launches)
+        avg_launch_s = (upd_ms * 1e-3) / max(1, upd_launches)
+        achieved = bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+        # GEMM chain: G_alg = 6*Ltau + 8*n_stack - 10 dense GEMMs of 2N^3 flop per sweep
+        g_alg = 6 * model.nt + 8 * model.n_stack - 10
+        out = {
+            "metric": "MC sweeps/sec, 2D Hubbard N=256 Ltau=200", "value": total_sweeps / dt, "unit": "sweeps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{args.config}: {model.L1}x{model.L2} Hubbard U={model.U} beta={model.beta} Ltau={model.nt} n_stab={model.n_stab} t=1 mu=-0.1",
+                       "chains_per_gpu": C, "n_chains_total": world * C, "parallelism": f"independent chains, {world} gpu x {C} chain"},
+            "acceptance": acc_rate, "max_wrap_err": s1.max_err, "mean_wrap_err": s1.mean_err,
+            "roofline": {"kernel": "local-update slice kernels (scan_kernel + flush_kernel)", "bound": "hbm",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_launch_s * 1e3,
+                         "launches": upd_launches, "accepted": upd_acc,
+                         "time_share_of_sweep": (upd_ms * 1e-3) / dt},
+            "gemm_chain": {"algorithmic_gemms_per_sweep": g_alg, "flop_per_sweep": g_alg * 2.0 * n ** 3,
+                           "peak_tflops": FP64_MFMA_PEAK_TFLOPS},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(model, 12345, args.cpu_budget)
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if dist is not None:
+        dist.barrier(); dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
