@@ -100,6 +100,8 @@ int launch_lu(Mat A, int* perm, long perm_stride, double* logabsdet, int accumul
 // Solve A X = B with the factors above, n right-hand sides.
 //   mode 0: X holds B on entry, overwritten by the solution.
 //   mode 1: B = diag(dg); X is overwritten.
+//   mode 2: "LU" is the R of a to_LDR result and perm its jpvt: X = R^-1 diag(dg) by a permuted
+//           triangular back substitution (no factorisation needed).
 int launch_lu_solve(CMat LU, const int* perm, long perm_stride, Mat X, CVec dg, int mode, int n, int n_chains, hipStream_t s);
 
 // ---- update.hip ---------------------------------------------------------------

@@ -35,6 +35,8 @@ const char* get_error() { return g_err.c_str(); }
 // ---------------------------------------------------------------------------
 struct LdrRef {                 // a batched LDR triple in HBM
     Mat L; Vec d; Mat R;
+    int* jpvt = nullptr;        // [C][n] pivot order storage of this triple (may be null)
+    bool* tri = nullptr;        // host flag: R is the permuted-triangular factor of ONE to_LDR (jpvt valid)
 };
 
 struct Ctx {
@@ -79,21 +81,33 @@ struct Ctx {
         return launch_gemm(g, C, stream);
     }
     // stablelinalg::to_LDR (source/stablelinalg.cpp:35-55); A is destroyed
-    int to_ldr(Mat A, LdrRef out) {
-        QrWork w{V(7).p, (long)n, jpvt(), (long)n};
+    // `direct`: out.R receives the QR's own R factor (not a product), so out can take the
+    // triangular fast path later; its pivot order is written straight into out.jpvt.
+    int to_ldr(Mat A, LdrRef out, bool direct = true) {
+        const bool keep = direct && out.jpvt != nullptr;
+        QrWork w{V(7).p, (long)n, keep ? out.jpvt : jpvt(), (long)n};
+        if (out.tri) *out.tri = keep;
         return launch_to_ldr(A, out.L, out.d, out.R, w, n, C, stream);
+    }
+    // X = F.R^-1 diag(dinv): permuted triangular solve when F.R is a single QR factor, LU otherwise
+    int r_inverse_scaled(LdrRef F, CVec dinv, Mat X, Mat lu_scratch) {
+        if (F.tri && *F.tri && F.jpvt) return launch_lu_solve(F.R, F.jpvt, n, X, dinv, 2, n, C, stream);
+        DQ_TRY(launch_copy(F.R, lu_scratch, nn, C, stream));
+        DQ_TRY(launch_lu(lu_scratch, lperm(), n, nullptr, 0, info(), n, C, stream));
+        return launch_lu_solve(lu_scratch, lperm(), n, X, dinv, 1, n, C, stream);
     }
     // stablelinalg::mat_mul_ldr (source/stablelinalg.cpp:69-79): out = M * F   (uses T0,T1)
     int mat_mul_ldr(CMat M, LdrRef F, LdrRef out) {
         DQ_TRY(gemm(M, F.L, T(0), CVec(), CVec(), CVec(F.d)));           // (M L) diag(d)
         LdrRef q{out.L, out.d, T(1)};
         DQ_TRY(to_ldr(T(0), q));
+        if (out.tri) *out.tri = false;                                   // R becomes a product
         return gemm(T(1), F.R, out.R);                                   // r * R
     }
     // stablelinalg::ldr_mul_mat (source/stablelinalg.cpp:57-67): out = F * M   (uses T0,T1)
     int ldr_mul_mat(LdrRef F, CMat M, LdrRef out) {
         DQ_TRY(gemm(F.R, M, T(0), CVec(F.d)));                            // diag(d) (R M)
-        LdrRef q{T(1), out.d, out.R};
+        LdrRef q{T(1), out.d, out.R, out.jpvt, out.tri};                  // R = the QR's own factor
         DQ_TRY(to_ldr(T(0), q));
         return gemm(F.L, T(1), out.L);                                   // L * q
     }
@@ -102,6 +116,7 @@ struct Ctx {
         DQ_TRY(gemm(F1.R, F2.L, T(0), CVec(F1.d), CVec(), CVec(F2.d)));    // diag(d1) (R1 L2) diag(d2)
         LdrRef q{T(1), out.d, T(2)};
         DQ_TRY(to_ldr(T(0), q));
+        if (out.tri) *out.tri = false;
         DQ_TRY(gemm(F1.L, T(1), out.L));
         return gemm(T(2), F2.R, out.R);
     }
@@ -110,9 +125,7 @@ struct Ctx {
     // log|det M| comes from that same factorisation (det M^T = det M).
     int inv_I_plus_ldr(LdrRef F, Mat G, double* logdet /*device, C*/) {
         DQ_TRY(launch_split_d(F.d, V(0), V(1), logdet, n, C, stream));                 // V0 = 1/Dl, V1 = Ds, logdet = sum log Dl
-        DQ_TRY(launch_copy(F.R, T(0), nn, C, stream));
-        DQ_TRY(launch_lu(T(0), lperm(), n, nullptr, 0, info(), n, C, stream));
-        DQ_TRY(launch_lu_solve(T(0), lperm(), n, T(1), V(0), 1, n, C, stream));         // X = R^-1 diag(1/Dl)
+        DQ_TRY(r_inverse_scaled(F, V(0), T(1), T(0)));                                  // X = R^-1 diag(1/Dl)
         DQ_TRY(launch_add_scaled_cols(T(1), F.L, V(1), T(2), n, C, stream));            // M = X + L diag(Ds)
         DQ_TRY(launch_transpose_scale(T(2), T(3), CVec(), n, C, stream));               // M^T
         DQ_TRY(launch_lu(T(3), lperm(), n, logdet, 1, info(), n, C, stream));           // logdet += log|det M|
@@ -124,9 +137,7 @@ struct Ctx {
     int inv_I_plus_ldr_mul_ldr(LdrRef F1, LdrRef F2, Mat G) {
         DQ_TRY(launch_split_d(F1.d, V(0), V(1), nullptr, n, C, stream));               // 1/D1l, D1s
         DQ_TRY(launch_split_d(F2.d, V(2), V(3), nullptr, n, C, stream));               // 1/D2l, D2s
-        DQ_TRY(launch_copy(F2.R, T(0), nn, C, stream));
-        DQ_TRY(launch_lu(T(0), lperm(), n, nullptr, 0, info(), n, C, stream));
-        DQ_TRY(launch_lu_solve(T(0), lperm(), n, T(1), V(2), 1, n, C, stream));         // X = R2^-1 diag(1/D2l)
+        DQ_TRY(r_inverse_scaled(F2, V(2), T(1), T(0)));                                 // X = R2^-1 diag(1/D2l)
         DQ_TRY(gemm(F1.L, T(1), T(2), V(0), CVec(), CVec(), 1));                        // TermA = diag(1/D1l) L1^T X
         DQ_TRY(gemm(F1.R, F2.L, T(2), V(1), CVec(), V(3), 0, 1));                       // M = TermA + diag(D1s) R1 L2 diag(D2s)
         DQ_TRY(launch_transpose_scale(F1.L, T(3), V(0), n, C, stream));                 // RHS = diag(1/D1l) L1^T
@@ -155,6 +166,8 @@ struct Engine {
     double* bb0 = nullptr; double* bb1 = nullptr;                // Bbar ping-pong
     double* stackL = nullptr; double* stackD = nullptr; double* stackR = nullptr;
     double* tmpL = nullptr; double* tmpD = nullptr; double* tmpR = nullptr;   // one spare LDR (init_stacks)
+    int* stackP = nullptr;                                       // [n_stack][C][n] pivot order of each entry's R
+    std::unique_ptr<bool[]> stack_tri;                           // [n_stack] R is a single permuted-triangular factor
     double* logdet = nullptr;                                    // [C]
     int32_t* rs_perm = nullptr; uint8_t* rs_k = nullptr; double* rs_u = nullptr;   // [C][nt][n]
     void* h_stage = nullptr; size_t h_stage_bytes = 0;           // pinned staging for the random stream
@@ -173,7 +186,10 @@ struct Engine {
     double upd_ms = 0.0; long long upd_launches = 0; long long upd_accept_base = 0;
 
     Mat mG() const { return Mat{G, nn}; }
-    LdrRef stk(int i) const { return LdrRef{Mat{stackL + (long)i * C * nn, nn}, Vec{stackD + (long)i * C * n, (long)n}, Mat{stackR + (long)i * C * nn, nn}}; }
+    LdrRef stk(int i) const {
+        return LdrRef{Mat{stackL + (long)i * C * nn, nn}, Vec{stackD + (long)i * C * n, (long)n}, Mat{stackR + (long)i * C * nn, nn},
+                      stackP + (long)i * C * n, &stack_tri[i]};
+    }
     CVec ev(int l) const { return CVec(expv + (long)l * n, (long)nt * n); }
     CVec iev(int l) const { return CVec(invexpv + (long)l * n, (long)nt * n); }
     int stack_idx(int l) const { return l / n_stab; }            // include/dqmc.h:47
@@ -183,7 +199,7 @@ struct Engine {
         if (s) (void)hipStreamSynchronize(s);
         for (auto& p : ev_pairs) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
         if (stage_free) (void)hipEventDestroy(stage_free);
-        void* ptrs[] = {expK, invexpK, fields, expv, invexpv, tabs, tab8, G, Gtmp, bb0, bb1, stackL, stackD, stackR, tmpL, tmpD, tmpR,
+        void* ptrs[] = {stackP, expK, invexpK, fields, expv, invexpv, tabs, tab8, G, Gtmp, bb0, bb1, stackL, stackD, stackR, tmpL, tmpD, tmpR,
                         logdet, rs_perm, rs_k, rs_u, Upanel, Wpanel, state, acc, err, dstats, r1scratch};
         for (void* p : ptrs) if (p) (void)hipFree(p);
         if (h_stage) (void)hipHostFree(h_stage);
@@ -204,6 +220,7 @@ struct Engine {
         DQ_TRY(dalloc(&tabs, C)); DQ_TRY(dalloc(&tab8, (size_t)C * 8));
         DQ_TRY(dalloc(&G, C * nn)); DQ_TRY(dalloc(&Gtmp, C * nn)); DQ_TRY(dalloc(&bb0, C * nn)); DQ_TRY(dalloc(&bb1, C * nn));
         DQ_TRY(dalloc(&stackL, (size_t)n_stack * C * nn)); DQ_TRY(dalloc(&stackD, (size_t)n_stack * C * n)); DQ_TRY(dalloc(&stackR, (size_t)n_stack * C * nn));
+        DQ_TRY(dalloc(&stackP, (size_t)n_stack * C * n)); stack_tri.reset(new bool[n_stack]());
         DQ_TRY(dalloc(&tmpL, C * nn)); DQ_TRY(dalloc(&tmpD, (size_t)C * n)); DQ_TRY(dalloc(&tmpR, C * nn));
         DQ_TRY(dalloc(&logdet, C));
         DQ_TRY(dalloc(&rs_perm, (size_t)C * nt * n)); DQ_TRY(dalloc(&rs_k, (size_t)C * nt * n)); DQ_TRY(dalloc(&rs_u, (size_t)C * nt * n));

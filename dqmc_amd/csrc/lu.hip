@@ -4,40 +4,48 @@
 // dgetrf (partial pivoting) + dgetrs.
 //
 //   lu_kernel        one 1024-thread workgroup per chain, right-looking
-//                    elimination streaming the trailing matrix from L2: wave w
-//                    owns trailing columns k+1+w, +16, ...; lanes own rows, so
-//                    every access is 512-byte coalesced and the update needs no
-//                    reduction.  Emits the row permutation (perm[r] = source
-//                    row of row r of P*A) and sum log|u_kk|.
-//   lu_solve_kernel  P A = L U, solve A X = B for n right-hand sides.  Columns
-//                    of X are independent: grid = (n/16 column tiles) x chains,
-//                    each wave keeps 4 columns in registers (lanes <-> rows) and
-//                    runs the forward (unit L) and backward (U) substitutions
-//                    with the pivot element broadcast by a lane shuffle: no LDS,
-//                    no barriers.
+//                    elimination streaming the trailing matrix from L2.  Rows
+//                    are NOT swapped: perm[k] records the pivot row of step k
+//                    and the factors stay in the original row order (row
+//                    perm[k] holds row k of U and of the unit-lower L).  Wave w
+//                    owns columns w, w+16, ...; lanes own rows; a wave streams
+//                    its trailing columns in batches (all loads in flight
+//                    before the first use), takes u_c = A[p, c] out of the
+//                    column it just loaded with a lane shuffle, and parks the
+//                    updated column k+1 in LDS, so the pivot search and the
+//                    multipliers of the next step touch no global memory.
+//                    Emits perm and sum log|u_kk|.
+//   lu_solve_kernel  solve A X = B for n right-hand sides.  Columns of X are
+//                    independent: grid = (n/16 column tiles) x chains, each
+//                    wave keeps 4 columns in registers (lane <-> pivot
+//                    position) and runs the forward (unit L) and backward (U)
+//                    substitutions with the pivot element broadcast by a lane
+//                    shuffle: no LDS, no barriers.
 #include "common.h"
 
 namespace dq {
 
 template <int NR>
 __global__ __launch_bounds__(1024) void lu_kernel(Mat Am, int* perm_p, long perm_stride, double* logabsdet, int accumulate, int* info, int n) {
-    __shared__ double lvec[1024], urow[1024];
+    __shared__ double lvec[1024], nextcol[1024];
     __shared__ double redv[16];
     __shared__ int redi[16];
+    __shared__ int rowpos[1024];      // -1 = live row, else the step at which it became a pivot row
     __shared__ int perm[1024];
     __shared__ int s_bad;
+    constexpr int CB = NR <= 4 ? 8 : (NR <= 9 ? 4 : 2);
     const int chain = blockIdx.y;
     double* __restrict__ A = Am.at(chain);
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    if (t < n) perm[t] = t;
+    if (t < n) { rowpos[t] = -1; nextcol[t] = A[t]; }
     if (t == 0) s_bad = 0;
     double logsum = 0.0;      // thread 0 only
     __syncthreads();
 
     for (int k = 0; k < n; ++k) {
-        // (a) pivot search: first max of |A[k:, k]|
-        double best = -1.0; int bi = k;
-        if (t >= k && t < n) { best = fabs(A[t + (long)n * k]); bi = t; }
+        // (a) pivot search over the live rows of column k (LDS image): first max of |a|
+        double best = -1.0; int bi = n;
+        if (t < n && rowpos[t] < 0) { best = fabs(nextcol[t]); bi = t; }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             const double ob = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
@@ -48,31 +56,49 @@ __global__ __launch_bounds__(1024) void lu_kernel(Mat Am, int* perm_p, long perm
         best = redv[0]; bi = redi[0];
 #pragma unroll
         for (int q = 1; q < 16; ++q) { const double ob = redv[q]; const int oi = redi[q]; if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; } }
-        const int p = bi;
-        // (b) swap rows k <-> p (thread t <-> column t), publish row k of U
+        const int p = bi < n ? bi : 0;
+        const double piv = nextcol[p];
+        // (b) multipliers of the live rows
         if (t < n) {
-            double akc = A[k + (long)n * t];
-            if (p != k) { const double apc = A[p + (long)n * t]; A[p + (long)n * t] = akc; A[k + (long)n * t] = apc; akc = apc; }
-            urow[t] = akc;
+            double l = 0.0;
+            if (rowpos[t] < 0 && t != p) { l = nextcol[t] / piv; A[t + (long)n * k] = l; }
+            lvec[t] = l;
         }
+        __syncthreads();                 // rowpos / nextcol reads done before they change
         if (t == 0) {
-            if (p != k) { const int tmp = perm[k]; perm[k] = perm[p]; perm[p] = tmp; }
+            rowpos[p] = k; perm[k] = p;
             if (!(best > 0.0)) s_bad = 1;
             logsum += log(best);
         }
-        __syncthreads();
-        // (c) multipliers
-        const double piv = urow[k];
-        if (t > k && t < n) { const double l = A[t + (long)n * k] / piv; A[t + (long)n * k] = l; lvec[t] = l; }
-        __syncthreads();
-        // (d) trailing update A[r,c] -= l_r u_c
+        // (c) trailing update A[r,c] -= l_r * A[p,c] on this wave's columns c > k
         double lr[NR];
 #pragma unroll
-        for (int q = 0; q < NR; ++q) { const int r = lane + 64 * q; lr[q] = (r > k && r < n) ? lvec[r] : 0.0; }
-        for (int c = k + 1 + wave; c < n; c += 16) {
-            const double uc = urow[c];
+        for (int q = 0; q < NR; ++q) { const int r = lane + 64 * q; lr[q] = (r < n) ? lvec[r] : 0.0; }
+        const int pq = p >> 6, pl = p & 63;
+        int first = wave; if (first <= k) first += 16 * ((k - first) / 16 + 1);
+        for (int cb = first; cb < n; cb += 16 * CB) {
+            double a[CB][NR];
 #pragma unroll
-            for (int q = 0; q < NR; ++q) { const int r = lane + 64 * q; if (r > k && r < n) A[r + (long)n * c] -= lr[q] * uc; }
+            for (int j = 0; j < CB; ++j) {
+                const int c = cb + 16 * j;
+#pragma unroll
+                for (int q = 0; q < NR; ++q) { const int r = lane + 64 * q; a[j][q] = (c < n && r < n) ? A[r + (long)n * c] : 0.0; }
+            }
+#pragma unroll
+            for (int j = 0; j < CB; ++j) {
+                const int c = cb + 16 * j;
+                if (c >= n) continue;
+                double up = 0.0;
+#pragma unroll
+                for (int q = 0; q < NR; ++q) if (q == pq) up = a[j][q];
+                const double uc = __shfl(up, pl, 64);
+#pragma unroll
+                for (int q = 0; q < NR; ++q) {
+                    const int r = lane + 64 * q;
+                    if (lr[q] != 0.0) { a[j][q] -= lr[q] * uc; A[r + (long)n * c] = a[j][q]; }
+                    if (c == k + 1 && r < n) nextcol[r] = a[j][q];
+                }
+            }
         }
         __syncthreads();
     }
@@ -83,8 +109,14 @@ __global__ __launch_bounds__(1024) void lu_kernel(Mat Am, int* perm_p, long perm
     }
 }
 
+// P A = L U with the factors in A's original row order: row perm[k] of LU holds
+// U[k, k:] and L[k, :k].  Lane/register position r of x below is the PIVOT position.
 // mode 0: B = X on entry (dense RHS, overwritten by the solution)
 // mode 1: B = diag(dg) (X overwritten)
+// mode 2: LU holds R = R1 * Pi^T of a to_LDR result (column perm[j] of R is column j of the
+//         upper-triangular R1; source/stablelinalg.cpp:51-52); X = R^-1 diag(dg) = Pi R1^-1 diag(dg)
+//         by back substitution only -- the permuted triangular solve that replaces the LU behind
+//         arma::solve(X, R, diagmat) at source/stablelinalg.cpp:112,147.
 template <int NR>
 __global__ __launch_bounds__(256) void lu_solve_kernel(CMat LUm, const int* perm_p, long perm_stride, Mat Xm, CVec dg, int mode, int n) {
     constexpr int CW = 4;
@@ -95,22 +127,29 @@ __global__ __launch_bounds__(256) void lu_solve_kernel(CMat LUm, const int* perm
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c0 = blockIdx.x * 16 + wave * CW;
     if (c0 >= n) return;
-    double x[CW][NR];
+    double x[CW][NR]; int prow[NR];
 #pragma unroll
     for (int k = 0; k < NR; ++k) {
         const int r = lane + 64 * k;
-        const int src = (r < n) ? perm[r] : 0;
+        prow[k] = (r < n) ? perm[r] : 0;
 #pragma unroll
         for (int cc = 0; cc < CW; ++cc) {
             const int c = c0 + cc;
             double v = 0.0;
-            if (r < n && c < n) v = (mode == 1) ? (src == c ? dg.at(chain)[c] : 0.0) : X[src + (long)n * c];
+            if (r < n && c < n) {
+                if (mode == 0) v = X[prow[k] + (long)n * c];
+                else if (mode == 1) v = (prow[k] == c) ? dg.at(chain)[c] : 0.0;
+                else v = (r == c) ? dg.at(chain)[c] : 0.0;
+            }
             x[cc][k] = v;
         }
     }
+    const bool tri = mode == 2;
+    const int kmax = tri ? min(c0 + CW - 1, n - 1) : n - 1;      // R1^-1 is upper triangular
     // forward substitution, unit lower L
 #pragma unroll
     for (int q = 0; q < NR; ++q) {
+        if (tri) break;
         for (int kk = 0; kk < 64; ++kk) {
             const int k = 64 * q + kk;
             if (k >= n) break;
@@ -121,7 +160,7 @@ __global__ __launch_bounds__(256) void lu_solve_kernel(CMat LUm, const int* perm
             for (int k2 = q; k2 < NR; ++k2) {
                 const int r = lane + 64 * k2;
                 if (r > k && r < n) {
-                    const double l = LU[r + (long)n * k];
+                    const double l = LU[prow[k2] + (long)n * k];
 #pragma unroll
                     for (int cc = 0; cc < CW; ++cc) x[cc][k2] -= l * xk[cc];
                 }
@@ -133,8 +172,10 @@ __global__ __launch_bounds__(256) void lu_solve_kernel(CMat LUm, const int* perm
     for (int q = NR - 1; q >= 0; --q) {
         for (int kk = 63; kk >= 0; --kk) {
             const int k = 64 * q + kk;
-            if (k >= n) continue;
-            const double ukk = LU[k + (long)n * k];
+            if (k > kmax) continue;
+            const int pk = __shfl(prow[q], kk, 64);                 // LU: pivot row of step k; tri: column of R holding R1[:, k]
+            const long colk = tri ? (long)n * pk : (long)n * k;
+            const double ukk = tri ? LU[k + colk] : LU[pk + colk];
             double xk[CW];
 #pragma unroll
             for (int cc = 0; cc < CW; ++cc) {
@@ -146,7 +187,7 @@ __global__ __launch_bounds__(256) void lu_solve_kernel(CMat LUm, const int* perm
             for (int k2 = 0; k2 <= q; ++k2) {
                 const int r = lane + 64 * k2;
                 if (r < k) {
-                    const double u = LU[r + (long)n * k];
+                    const double u = tri ? LU[r + colk] : LU[prow[k2] + colk];
 #pragma unroll
                     for (int cc = 0; cc < CW; ++cc) x[cc][k2] -= u * xk[cc];
                 }
@@ -157,7 +198,7 @@ __global__ __launch_bounds__(256) void lu_solve_kernel(CMat LUm, const int* perm
     for (int cc = 0; cc < CW; ++cc) {
         if (c0 + cc >= n) continue;
 #pragma unroll
-        for (int k = 0; k < NR; ++k) { const int r = lane + 64 * k; if (r < n) X[r + (long)n * (c0 + cc)] = x[cc][k]; }
+        for (int k = 0; k < NR; ++k) { const int r = lane + 64 * k; if (r < n) X[(tri ? prow[k] : r) + (long)n * (c0 + cc)] = x[cc][k]; }
     }
 }
 

@@ -3,84 +3,91 @@
 // explicit Q (dorgqr), d = |diag R0| and R = diag(1/d) R0 P^T.
 //
 //   qrcp_kernel   one 1024-thread workgroup per chain.  LAPACK dlaqp2
-//                 semantics: pivot = remaining column of largest partial norm
-//                 (lowest index on ties), Householder reflector from dlarfg
-//                 (beta = -sign(alpha)*norm), partial norms down-dated and
-//                 recomputed on cancellation.  The trailing matrix streams
-//                 from L2; wave w owns trailing columns i+1+w, i+1+w+16, ...,
-//                 a lane owns rows lane, lane+64, ... of a column, so global
-//                 accesses are 512-byte coalesced and the per-column dot is a
-//                 wave reduction.
+//                 semantics: pivot = remaining column of largest partial norm,
+//                 Householder reflector from dlarfg (beta = -sign(alpha)*norm),
+//                 partial norms down-dated and recomputed on cancellation.
+//                 Columns are NOT swapped: step i's reflector and R0 column
+//                 stay in the pivot column's own storage, jpvt[i] records it.
+//                 Wave w owns columns w, w+16, ...; a lane owns rows lane,
+//                 lane+64, ...; a wave streams its live columns from L2 in
+//                 batches of 8 (all loads in flight before the first use), the
+//                 per-column dot is a wave reduction.  While updating, each
+//                 wave keeps the register image of its best (largest-norm)
+//                 column and parks it in LDS, so the next step's pivot column
+//                 is read from LDS, not from L2: the serial part of a step
+//                 touches no global memory.
 //   formq_kernel  Q = H_0 ... H_{n-1} applied to I.  Column tiles of Q are
 //                 independent, so the grid is (n/16 tiles) x chains and every
 //                 wave keeps its 4 columns in registers: no LDS, no barriers.
-//   assemble_r_kernel  d and the un-pivoted, row-normalised R.
+//   assemble_r_kernel  d and the row-normalised R in original column order.
 #include "common.h"
+#include "wave.h"
 
 namespace dq {
 
-__device__ __forceinline__ double wave_sum(double x) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
-    return x;
-}
 
 // NR = rows per lane (n <= 64*NR)
 template <int NR>
 __global__ __launch_bounds__(1024) void qrcp_kernel(Mat Am, QrWork w, int n) {
-    __shared__ double vn1[1024], vn2[1024], v[1024];
-    __shared__ double red[16];
-    __shared__ int s_pvt;
-    __shared__ double s_alpha;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double* vn1 = reinterpret_cast<double*>(smem);          // [n]
+    double* vn2 = vn1 + n;                                  // [n]
+    double* v = vn2 + n;                                    // [n]   current Householder vector
+    double* candcol = v + n;                                // [16][n] best column of each wave
+    double* cand_v = candcol + 16 * (size_t)n;              // [16]
+    double* red = cand_v + 16;                              // [16]
+    int* cand_i = reinterpret_cast<int*>(red + 16);         // [16]
+    int* pivpos = cand_i + 16;                              // [n]  -1 = live, else pivot position
     const int chain = blockIdx.y;
     double* __restrict__ A = Am.at(chain);
     double* tau = w.tau + (long)chain * w.tau_stride;
     int* jpvt = w.jpvt + (long)chain * w.jpvt_stride;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const double tol3z = 1.0536712127723509e-08;    // sqrt(dlamch('Epsilon')) = sqrt(2^-53)
+    constexpr int QR_CB = NR <= 2 ? 8 : (NR <= 4 ? 4 : (NR <= 9 ? 2 : 1));   // columns a wave keeps in flight (register budget: 128 VGPRs)
 
-    // initial column norms
-    for (int c = wave; c < n; c += 16) {
-        double s = 0.0;
+    // initial column norms + each wave's best column
+    {
+        double bestn = -1.0; int besti = -1; double bcol[NR];
 #pragma unroll
-        for (int q = 0; q < NR; ++q) { const int r = lane + 64 * q; if (r < n) { const double x = A[r + (long)n * c]; s += x * x; } }
-        s = wave_sum(s);
-        if (lane == 0) { const double nn = sqrt(s); vn1[c] = nn; vn2[c] = nn; }
+        for (int q = 0; q < NR; ++q) bcol[q] = 0.0;
+        for (int c = wave; c < n; c += 16) {
+            double a[NR]; double s = 0.0;
+#pragma unroll
+            for (int q = 0; q < NR; ++q) { const int r = lane + 64 * q; a[q] = (r < n) ? A[r + (long)n * c] : 0.0; s += a[q] * a[q]; }
+            s = wave_sum(s);
+            const double nn = sqrt(s);
+            if (lane == 0) { vn1[c] = nn; vn2[c] = nn; pivpos[c] = -1; }
+            if (nn > bestn) {
+                bestn = nn; besti = c;
+#pragma unroll
+                for (int q = 0; q < NR; ++q) bcol[q] = a[q];
+            }
+        }
+        if (lane == 0) { cand_v[wave] = bestn; cand_i[wave] = besti; }
+#pragma unroll
+        for (int q = 0; q < NR; ++q) { const int r = lane + 64 * q; if (r < n) candcol[(size_t)wave * n + r] = bcol[q]; }
     }
-    if (t < n) jpvt[t] = t;
     __syncthreads();
 
     for (int i = 0; i < n; ++i) {
-        // (a) pivot: arg max of vn1[i..n), lowest index on ties
-        if (wave == 0) {
-            double best = -1.0; int bi = i;
-            for (int c = i + lane; c < n; c += 64) { const double x = vn1[c]; if (x > best) { best = x; bi = c; } }
+        // (a) pivot among the 16 wave candidates: largest norm, lowest column index on ties
+        double best = cand_v[0]; int bw = 0; int p = cand_i[0];
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const double ob = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
-                if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
-            }
-            if (lane == 0) s_pvt = bi;
+        for (int k = 1; k < 16; ++k) {
+            const double ob = cand_v[k]; const int oi = cand_i[k];
+            if (oi >= 0 && (p < 0 || ob > best || (ob == best && oi < p))) { best = ob; bw = k; p = oi; }
         }
-        __syncthreads();
-        const int pvt = s_pvt;
-        // (b) swap columns i <-> pvt; thread t keeps the new A[t, i]
-        double x = 0.0;
-        if (t < n) {
-            x = A[t + (long)n * pvt];
-            if (pvt != i) { const double y = A[t + (long)n * i]; A[t + (long)n * pvt] = y; A[t + (long)n * i] = x; }
-        }
-        if (t == 0 && pvt != i) { const int jp = jpvt[pvt]; jpvt[pvt] = jpvt[i]; jpvt[i] = jp; vn1[pvt] = vn1[i]; vn2[pvt] = vn2[i]; }
-        // (c) Householder vector (dlarfg)
-        double ss = (t > i && t < n) ? x * x : 0.0;
+        // (b) Householder vector from the parked image of column p (dlarfg)
+        const double x = (t >= i && t < n) ? candcol[(size_t)bw * n + t] : 0.0;
+        double ss = (t > i) ? x * x : 0.0;
         ss = wave_sum(ss);
         if (lane == 0) red[wave] = ss;
-        if (t == i) s_alpha = x;
         __syncthreads();
         double xnorm2 = 0.0;
 #pragma unroll
         for (int k = 0; k < 16; ++k) xnorm2 += red[k];
-        const double al = s_alpha;
+        const double al = candcol[(size_t)bw * n + i];
         double tau_i = 0.0, beta = al, scale = 0.0;
         if (xnorm2 != 0.0) {
             beta = -copysign(sqrt(al * al + xnorm2), al);
@@ -89,56 +96,87 @@ __global__ __launch_bounds__(1024) void qrcp_kernel(Mat Am, QrWork w, int n) {
         }
         if (t < n) {
             double vr = 0.0;
-            if (t == i) { vr = 1.0; A[t + (long)n * i] = beta; }
-            else if (t > i) { vr = x * scale; A[t + (long)n * i] = vr; }
+            if (t == i) { vr = 1.0; A[t + (long)n * p] = beta; }
+            else if (t > i) { vr = x * scale; A[t + (long)n * p] = vr; }
             v[t] = vr;
         }
-        if (t == 0) tau[i] = tau_i;
+        if (t == 0) { tau[i] = tau_i; jpvt[i] = p; pivpos[p] = i; }
         __syncthreads();
-        // (d) apply H to trailing columns, down-date norms
+        // (c) apply H to the live columns of this wave, down-date norms, track the wave's best column
         double vr[NR];
 #pragma unroll
         for (int q = 0; q < NR; ++q) { const int r = lane + 64 * q; vr[q] = (r < n) ? v[r] : 0.0; }
-        for (int c = i + 1 + wave; c < n; c += 16) {
-            double a[NR]; double s = 0.0;
+        double bestn = -1.0; int besti = -1; double bcol[NR];
 #pragma unroll
-            for (int q = 0; q < NR; ++q) { const int r = lane + 64 * q; a[q] = (r >= i && r < n) ? A[r + (long)n * c] : 0.0; s += a[q] * vr[q]; }
-            s = wave_sum(s) * tau_i;
-            double tail = 0.0, aic = 0.0;
+        for (int q = 0; q < NR; ++q) bcol[q] = 0.0;
+        for (int cb = wave; cb < n; cb += 16 * QR_CB) {
+            double a[QR_CB][NR]; bool live[QR_CB];
 #pragma unroll
-            for (int q = 0; q < NR; ++q) {
-                const int r = lane + 64 * q;
-                if (r >= i && r < n) {
-                    a[q] -= s * vr[q];
-                    if (tau_i != 0.0) A[r + (long)n * c] = a[q];
-                    if (r > i) tail += a[q] * a[q]; else aic = a[q];
+            for (int k = 0; k < QR_CB; ++k) {
+                const int c = cb + 16 * k;
+                live[k] = c < n && pivpos[c] < 0;
+#pragma unroll
+                for (int q = 0; q < NR; ++q) { const int r = lane + 64 * q; a[k][q] = (live[k] && r >= i && r < n) ? A[r + (long)n * c] : 0.0; }
+            }
+#pragma unroll
+            for (int k = 0; k < QR_CB; ++k) {
+                if (!live[k]) continue;
+                const int c = cb + 16 * k;
+                double s = 0.0;
+#pragma unroll
+                for (int q = 0; q < NR; ++q) s += a[k][q] * vr[q];
+                s = wave_sum(s) * tau_i;
+                double tail = 0.0, ai_q = 0.0;
+#pragma unroll
+                for (int q = 0; q < NR; ++q) {
+                    const int r = lane + 64 * q;
+                    if (r >= i && r < n) {
+                        a[k][q] -= s * vr[q];
+                        if (tau_i != 0.0) A[r + (long)n * c] = a[k][q];
+                        if (r > i) tail += a[k][q] * a[k][q];
+                    }
+                    if (q == (i >> 6)) ai_q = a[k][q];
+                }
+                const double aic = readlane_f64(ai_q, i & 63);   // A[i, c]
+                double n1 = vn1[c];
+                if (n1 != 0.0) {                         // norm down-date (dlaqp2)
+                    double temp = fabs(aic) / n1; temp = fmax(0.0, 1.0 - temp * temp);
+                    const double rr = n1 / vn2[c];
+                    const double temp2 = temp * rr * rr;
+                    if (temp2 <= tol3z) {
+                        tail = wave_sum(tail);
+                        n1 = (i + 1 < n) ? sqrt(tail) : 0.0;
+                        if (lane == 0) { vn1[c] = n1; vn2[c] = n1; }
+                    } else {
+                        n1 = n1 * sqrt(temp);
+                        if (lane == 0) vn1[c] = n1;
+                    }
+                }
+                if (n1 > bestn || besti < 0) {
+                    bestn = n1; besti = c;
+#pragma unroll
+                    for (int q = 0; q < NR; ++q) bcol[q] = a[k][q];
                 }
             }
-            // norm down-date (dlaqp2)
-            aic = wave_sum(aic);                 // exactly one lane holds row i
-            const double n1 = vn1[c];
-            if (n1 != 0.0) {
-                double temp = fabs(aic) / n1; temp = fmax(0.0, 1.0 - temp * temp);
-                const double rr = n1 / vn2[c];
-                const double temp2 = temp * rr * rr;
-                if (temp2 <= tol3z) {
-                    tail = wave_sum(tail);
-                    const double nn = (i + 1 < n) ? sqrt(tail) : 0.0;
-                    if (lane == 0) { vn1[c] = nn; vn2[c] = nn; }
-                } else if (lane == 0) vn1[c] = n1 * sqrt(temp);
-            }
+        }
+        if (lane == 0) { cand_v[wave] = bestn; cand_i[wave] = besti; }
+        if (besti >= 0) {
+#pragma unroll
+            for (int q = 0; q < NR; ++q) { const int r = lane + 64 * q; if (r < n) candcol[(size_t)wave * n + r] = bcol[q]; }
         }
         __syncthreads();
     }
 }
 
 // Each wave owns CW columns of Q in registers; applies H_i, i = n-1 .. 0.
+// Reflector i lives in column jpvt[i] of A (rows > i).
 template <int NR>
-__global__ __launch_bounds__(256) void formq_kernel(CMat Am, const double* tau_p, long tau_stride, Mat Qm, int n) {
+__global__ __launch_bounds__(256) void formq_kernel(CMat Am, const double* tau_p, long tau_stride, const int* jpvt_p, long jpvt_stride, Mat Qm, int n) {
     constexpr int CW = 4;
     const int chain = blockIdx.y;
     const double* __restrict__ A = Am.at(chain);
     const double* __restrict__ tau = tau_p + (long)chain * tau_stride;
+    const int* __restrict__ jpvt = jpvt_p + (long)chain * jpvt_stride;
     double* __restrict__ Q = Qm.at(chain);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c0 = blockIdx.x * 16 + wave * CW;
@@ -149,12 +187,23 @@ __global__ __launch_bounds__(256) void formq_kernel(CMat Am, const double* tau_p
 #pragma unroll
         for (int k = 0; k < NR; ++k) q[cc][k] = (lane + 64 * k == c0 + cc) ? 1.0 : 0.0;
     const int cmax = min(c0 + CW - 1, n - 1);
-    for (int i = cmax; i >= 0; --i) {
-        const double ti = tau[i];
-        if (ti == 0.0) continue;
-        double vr[NR];
+    // software prefetch of the next reflector hides the L2 latency of the serial chain
+    double vnext[NR]; double tnext = tau[cmax];
+    {
+        const int pc = jpvt[cmax];
 #pragma unroll
-        for (int k = 0; k < NR; ++k) { const int r = lane + 64 * k; vr[k] = (r > i && r < n) ? A[r + (long)n * i] : (r == i ? 1.0 : 0.0); }
+        for (int k = 0; k < NR; ++k) { const int r = lane + 64 * k; vnext[k] = (r > cmax && r < n) ? A[r + (long)n * pc] : (r == cmax ? 1.0 : 0.0); }
+    }
+    for (int i = cmax; i >= 0; --i) {
+        double vr[NR]; const double ti = tnext;
+#pragma unroll
+        for (int k = 0; k < NR; ++k) vr[k] = vnext[k];
+        if (i > 0) {
+            const int pc = jpvt[i - 1]; tnext = tau[i - 1];
+#pragma unroll
+            for (int k = 0; k < NR; ++k) { const int r = lane + 64 * k; vnext[k] = (r > i - 1 && r < n) ? A[r + (long)n * pc] : (r == i - 1 ? 1.0 : 0.0); }
+        }
+        if (ti == 0.0) continue;
 #pragma unroll
         for (int cc = 0; cc < CW; ++cc) {
             if (c0 + cc < i) continue;            // column still e_c: untouched by H_i
@@ -174,27 +223,35 @@ __global__ __launch_bounds__(256) void formq_kernel(CMat Am, const double* tau_p
     }
 }
 
-// d[j] = |R0[j,j]|;  R[:, jpvt[j]] = R0[:, j] / d   (source/stablelinalg.cpp:47-52)
+// d[j] = |R0[j,j]|;  R[:, jpvt[j]] = R0[:, j] / d   (source/stablelinalg.cpp:47-52).
+// Without column swaps R0[:, j] sits in column jpvt[j] of A, which is also its destination.
 __global__ void assemble_r_kernel(CMat Am, const int* jpvt_p, long jpvt_stride, Vec dv, Mat Rm, int n) {
     const int chain = blockIdx.y;
     const double* __restrict__ A = Am.at(chain);
     const int* jpvt = jpvt_p + (long)chain * jpvt_stride;
     double* __restrict__ R = Rm.at(chain);
     double* d = dv.at(chain);
-    const int j = blockIdx.x;                     // source column
-    const int dst = jpvt[j];
+    const int j = blockIdx.x;                     // pivot position
+    const int col = jpvt[j];
     for (int r = threadIdx.x; r < n; r += blockDim.x) {
         double val = 0.0;
-        if (r <= j) val = A[r + (long)n * j] / fabs(A[r + (long)n * r]);
-        R[r + (long)n * dst] = val;
+        if (r <= j) val = A[r + (long)n * col] / fabs(A[r + (long)n * jpvt[r]]);
+        R[r + (long)n * col] = val;
     }
-    if (threadIdx.x == 0) d[j] = fabs(A[j + (long)n * j]);
+    if (threadIdx.x == 0) d[j] = fabs(A[j + (long)n * col]);
 }
 
 template <int NR>
 static int launch_to_ldr_nr(Mat A, Mat L, Vec d, Mat R, QrWork w, int n, int n_chains, hipStream_t s) {
-    hipLaunchKernelGGL((qrcp_kernel<NR>), dim3(1, n_chains), dim3(1024), 0, s, A, w, n);
-    hipLaunchKernelGGL((formq_kernel<NR>), dim3((n + 15) / 16, n_chains), dim3(256), 0, s, CMat(A), (const double*)w.tau, w.tau_stride, L, n);
+    const size_t lds = sizeof(double) * ((size_t)3 * n + (size_t)16 * n + 32) + sizeof(int) * (16 + (size_t)n) + 64;
+    static bool attr_set = false;
+    if (!attr_set) {
+        DQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(qrcp_kernel<NR>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((qrcp_kernel<NR>), dim3(1, n_chains), dim3(1024), lds, s, A, w, n);
+    hipLaunchKernelGGL((formq_kernel<NR>), dim3((n + 15) / 16, n_chains), dim3(256), 0, s, CMat(A), (const double*)w.tau, w.tau_stride,
+                       (const int*)w.jpvt, w.jpvt_stride, L, n);
     hipLaunchKernelGGL(assemble_r_kernel, dim3(n, n_chains), dim3(128), 0, s, CMat(A), (const int*)w.jpvt, w.jpvt_stride, d, R, n);
     DQ_HIP(hipGetLastError());
     return 0;
