@@ -4,11 +4,11 @@ ARCH  ?= gfx950
 CXX   ?= g++
 HIPFLAGS ?= -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-function
 CSRC := dqmc_amd/csrc
-OBJS := $(CSRC)/gemm.o $(CSRC)/elementwise.o $(CSRC)/update.o $(CSRC)/qr.o $(CSRC)/lu.o $(CSRC)/engine.o
+OBJS := $(CSRC)/gemm.o $(CSRC)/elementwise.o $(CSRC)/update.o $(CSRC)/qr.o $(CSRC)/qr_onchip.o $(CSRC)/lu.o $(CSRC)/engine.o
 
 all: dqmc_amd/libdqmc_hip.so dqmc_amd/libdqmc_host.so oracle
 
-$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/common.h include/dqmc_hip.h
+$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/wave.h include/dqmc_hip.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 dqmc_amd/libdqmc_hip.so: $(OBJS)

@@ -22,6 +22,9 @@
 //   assemble_r_kernel  d and the row-normalised R in original column order.
 #include "common.h"
 #include "wave.h"
+#include <cstdlib>
+
+#define DQ_TRY_RC(expr) do { int _rc = (expr); if (_rc != 0) return _rc; } while (0)
 
 namespace dq {
 
@@ -241,8 +244,20 @@ __global__ void assemble_r_kernel(CMat Am, const int* jpvt_p, long jpvt_stride, 
     if (threadIdx.x == 0) d[j] = fabs(A[j + (long)n * col]);
 }
 
-template <int NR>
+int launch_qrcp_onchip(Mat A, QrWork w, int n, int n_chains, hipStream_t s);   // qr_onchip.hip
+
+// NRSEL = 0: on-chip QRCP (n <= 256); otherwise the streaming kernel with NRSEL rows per lane
+template <int NRSEL>
 static int launch_to_ldr_nr(Mat A, Mat L, Vec d, Mat R, QrWork w, int n, int n_chains, hipStream_t s) {
+    constexpr int NR = NRSEL == 0 ? 4 : NRSEL;
+    if (NRSEL == 0) {
+        DQ_TRY_RC(launch_qrcp_onchip(A, w, n, n_chains, s));
+        hipLaunchKernelGGL((formq_kernel<NR>), dim3((n + 15) / 16, n_chains), dim3(256), 0, s, CMat(A), (const double*)w.tau, w.tau_stride,
+                           (const int*)w.jpvt, w.jpvt_stride, L, n);
+        hipLaunchKernelGGL(assemble_r_kernel, dim3(n, n_chains), dim3(128), 0, s, CMat(A), (const int*)w.jpvt, w.jpvt_stride, d, R, n);
+        DQ_HIP(hipGetLastError());
+        return 0;
+    }
     const size_t lds = sizeof(double) * ((size_t)3 * n + (size_t)16 * n + 32) + sizeof(int) * (16 + (size_t)n) + 64;
     static bool attr_set = false;
     if (!attr_set) {
@@ -259,6 +274,8 @@ static int launch_to_ldr_nr(Mat A, Mat L, Vec d, Mat R, QrWork w, int n, int n_c
 
 int launch_to_ldr(Mat A, Mat L, Vec d, Mat R, QrWork w, int n, int n_chains, hipStream_t s) {
     if (n > 1024) { set_error("to_LDR kernel supports n <= 1024"); return -1; }
+    static const bool force_stream = getenv("DQMC_QR_STREAMING") != nullptr;    // A/B switch for tests and profiling
+    if (n <= 256 && !force_stream) return launch_to_ldr_nr<0>(A, L, d, R, w, n, n_chains, s);
     if (n <= 64) return launch_to_ldr_nr<1>(A, L, d, R, w, n, n_chains, s);
     if (n <= 128) return launch_to_ldr_nr<2>(A, L, d, R, w, n, n_chains, s);
     if (n <= 256) return launch_to_ldr_nr<4>(A, L, d, R, w, n, n_chains, s);

@@ -1,0 +1,295 @@
+// qr_onchip.hip -- column-pivoted Householder QR for n <= 256 with the whole
+// matrix resident in ONE compute unit's registers + LDS (no HBM/L2 traffic in
+// the 256-step serial loop).  Same algorithm and output format as the
+// streaming qrcp_kernel of qr.hip (LAPACK dlaqp2 semantics, reflectors and R0
+// left in place in A, jpvt/tau out); to_LDR = source/stablelinalg.cpp:35-55.
+//
+// Why: the streaming kernel is bound by what one CU can pull through its L1
+// (~64 B/clk): ~8*n^3 bytes per factorisation = 3.6 ms at n = 256, 40 % of a
+// sweep.  512 KiB of fp64 fits one CU: 512 threads x 96 doubles in VGPRs
+// (384 KiB) + 128 KiB of the 160 KiB LDS.
+//
+// Data layout (one 512-thread workgroup per chain, 8 waves, 2 per SIMD):
+//   lane = 16*cl + rg, wave w:  thread owns columns c = 32w + 8cl + kc (kc=0..7)
+//   and rows r = 16*b + rg (row block b = 0..15).  kc = 0..5 live in registers
+//   a[kc][b], kc = 6,7 in LDS (lcol[kc-6][b][thread], conflict-free).
+//   * the 16 row groups of a column sit in ONE DPP row of 16 lanes, so the
+//     Householder dot products reduce with 4 DPP steps: no LDS, no barrier;
+//   * a wave owns its 32 columns completely, so the update phase needs no
+//     cross-wave communication at all;
+//   * each v_r fetched from LDS feeds 8 columns (16 FMAs): LDS traffic stays far
+//     under the fp64 FMA time;
+//   * the step loop is unrolled over the 16 row blocks at compile time
+//     (qr_block<JB>): inside block JB every register index is static, row i
+//     (needed for the norm down-date) is register a[kc][JB], and the registers
+//     of finished row blocks are dead, which hands them back to the allocator --
+//     the register file is the scarce resource here (192 of 256 VGPRs hold data).
+// Pivot choice uses a 64-bit key (norm bits with the low 8 mantissa bits
+// replaced by 255 - column): columns whose norms agree to 2^-44 are ordered by
+// index, exactly equal norms pick the lowest index as LAPACK does.
+#include "common.h"
+#include "wave.h"
+
+namespace dq {
+
+namespace {
+
+constexpr int OC_N = 256;      // padded matrix size
+constexpr int OC_T = 512;      // threads
+constexpr int OC_KC = 8;       // columns per thread
+constexpr int OC_KR = 6;       // ... of which in registers
+
+__device__ __forceinline__ unsigned long long norm_key(double nrm, int c) {
+    return (1ULL << 63) | ((unsigned long long)__double_as_longlong(nrm) & ~0xFFULL) | (unsigned long long)(255 - c);
+}
+
+struct OcShared {
+    double* lcol;                 // [2][16][512]  columns kc = 6,7 of every thread
+    double* xbuf;                 // [256] pivot column image
+    double* vbuf;                 // [256] Householder vector
+    double* vn1;                  // [256]
+    double* vn2;                  // [256]
+    unsigned long long* keys;     // [8]
+    double* scal;                 // [0] = |x(i+1:)|^2
+    int* pposl;                   // [256] pivot position of a pivoted column
+};
+
+#define LCOL(kc, blk) sh.lcol[(((kc) - OC_KR) * 16 + (blk)) * OC_T + t]
+
+// All steps i in row block JB (i = 16*JB .. min(16*JB+15, n-1)).
+template <int JB>
+__device__ __forceinline__ void qr_block(double (&a)[OC_KR][16], int& livem, const OcShared& sh, double* __restrict__ A,
+                                         double* tau, int* jpvt, int n, int t, int lane, int wave, int rg, int cl, int cbase) {
+    constexpr int NJ = 16 - JB;                                     // live row blocks JB .. 15
+    const double tol3z = 1.0536712127723509e-08;                    // sqrt(2^-53)
+    const int i_end = min(16 * JB + 16, n);
+    for (int i = 16 * JB; i < i_end; ++i) {
+        // ---- [A] pivot + publish its column ----
+        unsigned long long best = sh.keys[0];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) { const unsigned long long o = sh.keys[k]; best = o > best ? o : best; }
+        const int p = 255 - (int)(best & 0xFFULL);
+        const int kcp = p & 7;
+        if (wave == (p >> 5)) {                // wave-uniform
+            const bool mine = cl == ((p & 31) >> 3);
+            double ss = 0.0;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int r = 16 * (JB + j) + rg;
+                double x = 0.0;
+#pragma unroll
+                for (int kc = 0; kc < OC_KR; ++kc) if (kcp == kc) x = a[kc][JB + j];
+                if (kcp == 6) x = LCOL(6, JB + j);
+                if (kcp == 7) x = LCOL(7, JB + j);
+                if (mine) sh.xbuf[r] = x;
+                if (r > i) ss += x * x;
+            }
+            ss = row16_sum(ss);                // every DPP row sums its own lanes; only the pivot's row is used
+            if (mine && rg == 0) sh.scal[0] = ss;
+        }
+        __syncthreads();
+        // ---- [B] Householder vector (dlarfg) ----
+        const double al = sh.xbuf[i];
+        const double xnorm2 = sh.scal[0];
+        double tau_i = 0.0, beta = al, scale = 0.0;
+        if (xnorm2 != 0.0) {
+            beta = -copysign(sqrt(al * al + xnorm2), al);
+            tau_i = (beta - al) / beta;
+            scale = 1.0 / (al - beta);
+        }
+        if (t < OC_N && t >= 16 * JB) {
+            const int r = t;
+            double vr = 0.0;
+            if (r == i) { vr = 1.0; if (r < n) A[r + (long)n * p] = beta; }
+            else if (r > i) { vr = sh.xbuf[r] * scale; if (r < n) A[r + (long)n * p] = vr; }
+            sh.vbuf[r] = vr;
+        }
+        if (t == 0) { tau[i] = tau_i; jpvt[i] = p; sh.pposl[p] = i; }
+        if ((p >> 3) == (cbase >> 3)) livem &= ~(1 << (p & 7));
+        __syncthreads();
+        // ---- [C] apply H to my live columns: two passes over the live row blocks, two blocks per trip ----
+        {
+            const double* vb = sh.vbuf + 16 * JB + rg;
+            double s[OC_KC];
+#pragma unroll
+            for (int kc = 0; kc < OC_KC; ++kc) s[kc] = 0.0;
+#pragma unroll
+            for (int j = 0; j < NJ; j += 2) {
+                const double v0 = vb[16 * j];
+                const double v1 = (j + 1 < NJ) ? vb[16 * (j + 1)] : 0.0;
+                const double l60 = LCOL(6, JB + j), l70 = LCOL(7, JB + j);
+                const double l61 = (j + 1 < NJ) ? LCOL(6, JB + j + 1) : 0.0, l71 = (j + 1 < NJ) ? LCOL(7, JB + j + 1) : 0.0;
+#pragma unroll
+                for (int kc = 0; kc < OC_KR; ++kc) { s[kc] += a[kc][JB + j] * v0; if (j + 1 < NJ) s[kc] += a[kc][JB + j + 1] * v1; }
+                s[6] += l60 * v0 + l61 * v1; s[7] += l70 * v0 + l71 * v1;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int kc = 0; kc < OC_KC; ++kc) { s[kc] = row16_sum(s[kc]) * tau_i; if (!(livem & (1 << kc))) s[kc] = 0.0; }
+#pragma unroll
+            for (int j = 0; j < NJ; j += 2) {
+                const double v0 = vb[16 * j];
+                const double v1 = (j + 1 < NJ) ? vb[16 * (j + 1)] : 0.0;
+#pragma unroll
+                for (int kc = 0; kc < OC_KR; ++kc) { a[kc][JB + j] -= s[kc] * v0; if (j + 1 < NJ) a[kc][JB + j + 1] -= s[kc] * v1; }
+                if (livem & 64) { LCOL(6, JB + j) -= s[6] * v0; if (j + 1 < NJ) LCOL(6, JB + j + 1) -= s[6] * v1; }
+                if (livem & 128) { LCOL(7, JB + j) -= s[7] * v0; if (j + 1 < NJ) LCOL(7, JB + j + 1) -= s[7] * v1; }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // ---- norm down-date (dlaqp2) by the lanes that hold row i (register a[kc][JB]), new keys ----
+        // Pass 1 finds the columns whose norm must be recomputed (cancellation), the rare pass 2
+        // recomputes them cooperatively, pass 3 applies the down-date and forms the pivot keys.
+        // One column at a time: nothing may be kept per column, the register file is full.
+        const bool own_row = rg == (i & 15);
+        int need = 0;
+        if (own_row) {
+#pragma unroll
+            for (int kc = 0; kc < OC_KC; ++kc) {
+                if (livem & (1 << kc)) {
+                    const double rv = kc < OC_KR ? a[kc < OC_KR ? kc : 0][JB] : LCOL(kc, JB);
+                    const double n1_ = sh.vn1[cbase + kc];
+                    if (n1_ != 0.0) {
+                        double temp = fabs(rv) / n1_; temp = fmax(0.0, 1.0 - temp * temp);
+                        const double rr = n1_ / sh.vn2[cbase + kc];
+                        if (temp * rr * rr <= tol3z) need |= 1 << kc;
+                    }
+                }
+            }
+        }
+        need = __shfl(need, (lane & 48) | (i & 15), 64);      // share with the other 15 lanes of the DPP row
+        if (__any(need != 0)) {
+#pragma unroll
+            for (int kc = 0; kc < OC_KC; ++kc) {
+                if (__any((need >> kc) & 1)) {
+                    double tl = 0.0;
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        if (16 * (JB + j) + rg > i) {
+                            const double x = kc < OC_KR ? a[kc < OC_KR ? kc : 0][JB + j] : LCOL(kc, JB + j);
+                            tl += x * x;
+                        }
+                    }
+                    tl = row16_sum(tl);
+                    if (own_row && ((need >> kc) & 1)) {
+                        const double nn = (i + 1 < n) ? sqrt(tl) : 0.0;
+                        sh.vn1[cbase + kc] = nn; sh.vn2[cbase + kc] = nn;
+                    }
+                }
+            }
+        }
+        {
+            unsigned long long key = 0;
+            if (own_row) {
+#pragma unroll
+                for (int kc = 0; kc < OC_KC; ++kc) {
+                    if (livem & (1 << kc)) {
+                        double nn = sh.vn1[cbase + kc];
+                        if (nn != 0.0 && !((need >> kc) & 1)) {
+                            const double rv = kc < OC_KR ? a[kc < OC_KR ? kc : 0][JB] : LCOL(kc, JB);
+                            double temp = fabs(rv) / nn; temp = fmax(0.0, 1.0 - temp * temp);
+                            nn = nn * sqrt(temp);
+                            sh.vn1[cbase + kc] = nn;
+                        }
+                        const unsigned long long k = norm_key(nn, cbase + kc); key = k > key ? k : key;
+                    }
+                }
+            }
+            key = wave_max_u64(key);
+            if (lane == 0) sh.keys[wave] = key;
+        }
+        // ---- end of the row block: it is final -> store it as R0 ----
+        if (i == i_end - 1) {
+            const int r = 16 * JB + rg;
+            if (r < n) {
+                // live columns: every row <= i is an R0 entry.  Pivoted columns: rows above the pivot
+                // position are R0 entries; the diagonal (beta) and the reflector below it are already in A.
+#pragma unroll
+                for (int kc = 0; kc < OC_KC; ++kc) {
+                    if (cbase + kc < n && ((livem & (1 << kc)) ? r <= i : r < sh.pposl[cbase + kc]))
+                        A[r + (long)n * (cbase + kc)] = kc < OC_KR ? a[kc < OC_KR ? kc : 0][JB] : LCOL(kc, JB);
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(OC_T) void qrcp_onchip_kernel(Mat Am, QrWork w, int n) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    OcShared sh;
+    sh.lcol = reinterpret_cast<double*>(smem);
+    sh.xbuf = sh.lcol + 2 * 16 * OC_T;
+    sh.vbuf = sh.xbuf + OC_N;
+    sh.vn1 = sh.vbuf + OC_N;
+    sh.vn2 = sh.vn1 + OC_N;
+    sh.keys = reinterpret_cast<unsigned long long*>(sh.vn2 + OC_N);
+    sh.scal = reinterpret_cast<double*>(sh.keys + 8);
+    sh.pposl = reinterpret_cast<int*>(sh.scal + 8);
+
+    const int chain = blockIdx.y;
+    double* __restrict__ A = Am.at(chain);
+    double* tau = w.tau + (long)chain * w.tau_stride;
+    int* jpvt = w.jpvt + (long)chain * w.jpvt_stride;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int rg = lane & 15, cl = lane >> 4;
+    const int cbase = 32 * wave + 8 * cl;
+
+    double a[OC_KR][16];
+    int livem = 0;                                                  // bit kc: my column kc has not been pivoted yet
+#pragma unroll
+    for (int kc = 0; kc < OC_KC; ++kc) if (cbase + kc < n) livem |= 1 << kc;       // padding columns are never live
+    if (t < OC_N) sh.pposl[t] = OC_N;
+
+    // ---- load, initial norms, initial keys ----
+    {
+        double nrm[OC_KC];
+#pragma unroll
+        for (int kc = 0; kc < OC_KC; ++kc) nrm[kc] = 0.0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int r = 16 * j + rg;
+#pragma unroll
+            for (int kc = 0; kc < OC_KC; ++kc) {
+                const double x = (r < n && cbase + kc < n) ? A[r + (long)n * (cbase + kc)] : 0.0;
+                if (kc < OC_KR) a[kc < OC_KR ? kc : 0][j] = x; else LCOL(kc, j) = x;
+                nrm[kc] += x * x;
+            }
+        }
+        unsigned long long key = 0;
+#pragma unroll
+        for (int kc = 0; kc < OC_KC; ++kc) {
+            const double nn = sqrt(row16_sum(nrm[kc]));
+            if (rg == 0) {
+                sh.vn1[cbase + kc] = nn; sh.vn2[cbase + kc] = nn;
+                if (livem & (1 << kc)) { const unsigned long long k = norm_key(nn, cbase + kc); key = k > key ? k : key; }
+            }
+        }
+        key = wave_max_u64(key);
+        if (lane == 0) sh.keys[wave] = key;
+    }
+    __syncthreads();
+
+#define DQ_QR_BLOCK(JB) if (16 * JB < n) qr_block<JB>(a, livem, sh, A, tau, jpvt, n, t, lane, wave, rg, cl, cbase);
+    DQ_QR_BLOCK(0) DQ_QR_BLOCK(1) DQ_QR_BLOCK(2) DQ_QR_BLOCK(3) DQ_QR_BLOCK(4) DQ_QR_BLOCK(5) DQ_QR_BLOCK(6) DQ_QR_BLOCK(7)
+    DQ_QR_BLOCK(8) DQ_QR_BLOCK(9) DQ_QR_BLOCK(10) DQ_QR_BLOCK(11) DQ_QR_BLOCK(12) DQ_QR_BLOCK(13) DQ_QR_BLOCK(14) DQ_QR_BLOCK(15)
+#undef DQ_QR_BLOCK
+}
+#undef LCOL
+
+int launch_qrcp_onchip(Mat A, QrWork w, int n, int n_chains, hipStream_t s) {
+    if (n > OC_N) { set_error("on-chip QRCP supports n <= 256"); return -1; }
+    const size_t lds = sizeof(double) * (2 * 16 * OC_T + 4 * OC_N + 8 + 8) + sizeof(int) * OC_N + 64;
+    static bool attr_set = false;
+    if (!attr_set) {
+        DQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(qrcp_onchip_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(qrcp_onchip_kernel, dim3(1, n_chains), dim3(OC_T), lds, s, A, w, n);
+    DQ_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace dq

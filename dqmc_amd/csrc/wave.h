@@ -34,6 +34,15 @@ __device__ __forceinline__ double wave_sum(double x) {
     return readlane_f64(x, 63);
 }
 
+// Sum over each 16-lane DPP row; every lane of a row receives its row's sum.
+__device__ __forceinline__ double row16_sum(double x) {
+    x += dpp_mov_f64<0xB1, 0xf>(x);
+    x += dpp_mov_f64<0x4E, 0xf>(x);
+    x += dpp_mov_f64<0x141, 0xf>(x);
+    x += dpp_mov_f64<0x140, 0xf>(x);
+    return x;
+}
+
 // butterfly sum with LDS-crossbar shuffles (reference implementation for tests)
 __device__ __forceinline__ double wave_sum_shfl(double x) {
 #pragma unroll
