@@ -6,7 +6,7 @@ HIPFLAGS ?= -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-functi
 CSRC := dqmc_amd/csrc
 OBJS := $(CSRC)/gemm.o $(CSRC)/elementwise.o $(CSRC)/update.o $(CSRC)/qr.o $(CSRC)/qr_onchip.o $(CSRC)/lu.o $(CSRC)/engine.o
 
-all: dqmc_amd/libdqmc_hip.so dqmc_amd/libdqmc_host.so oracle
+all: dqmc_amd/libdqmc_hip.so dqmc_amd/libdqmc_host.so dqmc_amd/dqmc_driver oracle
 
 $(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/wave.h include/dqmc_hip.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
@@ -17,11 +17,14 @@ dqmc_amd/libdqmc_hip.so: $(OBJS)
 dqmc_amd/libdqmc_host.so: dqmc_amd/host/host_capi.cpp dqmc_amd/host/dqmc_host.hpp include/dqmc_hip.h
 	$(CXX) -O2 -std=c++17 -fPIC -shared -Iinclude -Idqmc_amd/host -o $@ dqmc_amd/host/host_capi.cpp -ldl
 
+dqmc_amd/dqmc_driver: dqmc_amd/host/main.cpp dqmc_amd/host/dqmc_host.hpp include/dqmc_hip.h dqmc_amd/libdqmc_hip.so
+	$(CXX) -O2 -std=c++17 -Iinclude -Idqmc_amd/host -o $@ dqmc_amd/host/main.cpp -Ldqmc_amd -ldqmc_hip -Wl,-rpath,'$$ORIGIN'
+
 oracle:
 	$(MAKE) -C oracle
 
 clean:
-	rm -f $(CSRC)/*.o dqmc_amd/*.so
+	rm -f $(CSRC)/*.o dqmc_amd/*.so dqmc_amd/dqmc_driver
 	$(MAKE) -C oracle clean
 
 .PHONY: all oracle clean

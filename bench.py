@@ -69,16 +69,10 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # "nccl" is RCCL on ROCm
-    elif torch.cuda.is_available():
-        torch.cuda.set_device(local_rank)
+    from dqmc_amd.launch import barrier as dist_barrier, dist_init, finalize, max_over_ranks
+    d = dist_init()                       # WORLD_SIZE > 1: backend "nccl" (= RCCL) on GPUs
+    rank, world, local_rank = d.rank, d.world, d.local_rank
 
     import dqmc_amd
     lib = dqmc_amd.lib()
@@ -92,10 +86,7 @@ def main():
     rng = np.random.default_rng(777 + rank)
 
     def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+        dist_barrier(d)
 
     def sweep():
         eng.sweep_0_to_beta(*gen_streams(model, rng, C))
@@ -116,8 +107,7 @@ def main():
     upd_ms, upd_launches, upd_acc = eng.update_kernel_time()
     eng.set_profiling(False)
     st1 = eng.stats()
-    if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda"); dist.all_reduce(tt, op=dist.ReduceOp.MAX); dt = float(tt.item())
+    dt = max_over_ranks(d, dt)
 
     if rank == 0:
         n = model.n
@@ -151,8 +141,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(model, 12345, args.cpu_budget)
         print(json.dumps(out), flush=True)
     eng.close()
-    if dist is not None:
-        dist.barrier(); dist.destroy_process_group()
+    finalize(d)
 
 
 if __name__ == "__main__":

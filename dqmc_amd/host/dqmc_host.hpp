@@ -1,0 +1,442 @@
+// dqmc_host.hpp -- C++17 host facade over the C ABI (include/dqmc_hip.h).
+//
+// Mirrors the reference's source-level plugin surface for the equal-time
+// sweep path so that a main.cpp-shaped driver reads the same
+// (names, argument meaning, error behaviour):
+//
+//   utility::random / parameters      include/utility.h:19-48, :50-276
+//   Lattice                           include/lattice.h:14-137
+//   GHQField                          include/field.h:13-84
+//   AttractiveHubbard                 include/model.h:11-58, source/model.cpp:3-159
+//   GF, LDRStack                      include/stackngf.h:15-77
+//   DQMC                              include/dqmc.h:21-93
+//   update::local_update / partner_rank / replica_exchange   include/update.h:11-20
+//
+// Differences, all forced by where the state lives: matrices are plain
+// column-major std::vector<double> instead of arma::mat (Armadillo is not a
+// dependency); GF and LDRStack are thin handles onto HBM-resident state with
+// explicit download; update::local_update's per-site work runs on the GPU
+// inside DQMC::sweep_*, the host only draws the slice's random stream from
+// utility::random with exactly the reference's calls (draw_slice_stream).
+// Errors from the C ABI are rethrown as the exception types the reference
+// throws (std::runtime_error, std::out_of_range).
+#pragma once
+
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <fstream>
+#include <functional>
+#include <map>
+#include <random>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <sys/stat.h>
+#include <vector>
+
+#include "dqmc_hip.h"
+
+namespace utility {
+
+// include/utility.h:19-48
+class random {
+    std::mt19937 generator_;
+    std::uniform_int_distribution<int> dist_GHQField_;
+public:
+    explicit random(unsigned int seed) : generator_(seed), dist_GHQField_(0, 3) {}
+    bool bernoulli(double p) { std::bernoulli_distribution dist(p); return dist(generator_); }
+    int rand_GHQField() { return dist_GHQField_(generator_); }
+    std::mt19937& get_generator() { return generator_; }
+};
+
+// include/utility.h:50-276: INI reader (sections, '#'/';' comments, quotes,
+// '_' digit separators, bool words, comma lists).  Same keys as examples/parameters.in.
+class parameters {
+    std::map<std::string, std::map<std::string, std::string>> sections_;
+    static void trim(std::string& s) {
+        const char* ws = " \t\r\n";
+        const auto b = s.find_first_not_of(ws);
+        if (b == std::string::npos) { s.clear(); return; }
+        s = s.substr(b, s.find_last_not_of(ws) - b + 1);
+    }
+    static std::string strip_us(std::string v) { v.erase(std::remove(v.begin(), v.end(), '_'), v.end()); return v; }
+    void parse(std::istream& in) {
+        std::string line, section = "global";
+        while (std::getline(in, line)) {
+            const auto c = line.find_first_of("#;");
+            if (c != std::string::npos) line.resize(c);
+            trim(line);
+            if (line.empty()) continue;
+            if (line.front() == '[' && line.back() == ']') { section = line.substr(1, line.size() - 2); trim(section); continue; }
+            const auto eq = line.find('=');
+            if (eq == std::string::npos) continue;
+            std::string key = line.substr(0, eq), val = line.substr(eq + 1);
+            trim(key); trim(val);
+            if (val.size() >= 2 && ((val.front() == '"' && val.back() == '"') || (val.front() == '\'' && val.back() == '\''))) val = val.substr(1, val.size() - 2);
+            sections_[section][key] = val;
+        }
+    }
+public:
+    parameters() = default;
+    explicit parameters(const std::string& filename) {
+        std::ifstream f(filename);
+        if (!f.is_open()) throw std::runtime_error("Failed to open parameter file: " + filename);
+        parse(f);
+    }
+    static parameters from_string(const std::string& text) { parameters p; std::istringstream in(text); p.parse(in); return p; }
+    void set(const std::string& section, const std::string& key, const std::string& value) { sections_[section][key] = value; }
+
+    std::string getString(const std::string& section, const std::string& key) const {
+        const auto s = sections_.find(section);
+        if (s == sections_.end()) throw std::runtime_error("Section '" + section + "' not found");
+        const auto k = s->second.find(key);
+        if (k == s->second.end()) throw std::runtime_error("Key '" + key + "' not found in section '" + section + "'");
+        return k->second;
+    }
+    int getInt(const std::string& section, const std::string& key) const {
+        const std::string v = getString(section, key);
+        try { return std::stoi(strip_us(v)); } catch (const std::exception&) { throw std::runtime_error("Cannot convert '" + v + "' to integer for key '" + key + "'"); }
+    }
+    int getInt(const std::string& s, const std::string& k, int dflt) const { try { return getInt(s, k); } catch (...) { return dflt; } }
+    double getDouble(const std::string& section, const std::string& key) const {
+        const std::string v = getString(section, key);
+        try { return std::stod(strip_us(v)); } catch (const std::exception&) { throw std::runtime_error("Cannot convert '" + v + "' to double for key '" + key + "'"); }
+    }
+    double getDouble(const std::string& s, const std::string& k, double dflt) const { try { return getDouble(s, k); } catch (...) { return dflt; } }
+    bool getBool(const std::string& section, const std::string& key) const {
+        std::string v = getString(section, key);
+        std::transform(v.begin(), v.end(), v.begin(), [](unsigned char c) { return std::tolower(c); });
+        if (v == "true" || v == "1" || v == "yes" || v == "on") return true;
+        if (v == "false" || v == "0" || v == "no" || v == "off") return false;
+        throw std::runtime_error("Cannot convert '" + v + "' to boolean for key '" + key + "'");
+    }
+    bool getBool(const std::string& s, const std::string& k, bool dflt) const { try { return getBool(s, k); } catch (...) { return dflt; } }
+    std::vector<double> getDoubleVector(const std::string& section, const std::string& key) const {
+        std::vector<double> out; std::stringstream ss(getString(section, key)); std::string item;
+        while (std::getline(ss, item, ',')) {
+            trim(item); if (item.empty()) continue;
+            try { out.push_back(std::stod(strip_us(item))); } catch (const std::exception&) { throw std::runtime_error("Cannot convert '" + item + "' to double in list for key '" + key + "'"); }
+        }
+        return out;
+    }
+    bool hasSection(const std::string& s) const { return sections_.count(s) != 0; }
+    bool hasKey(const std::string& s, const std::string& k) const { const auto it = sections_.find(s); return it != sections_.end() && it->second.count(k) != 0; }
+};
+
+}  // namespace utility
+
+// include/lattice.h:14-137
+class Lattice {
+    std::array<double, 2> a1_, a2_;
+    std::vector<std::array<double, 2>> orbs_;
+    int L1_, L2_, n_orb_;
+    std::array<double, 2> b1_, b2_;
+    std::vector<std::array<double, 2>> k_points_;
+public:
+    Lattice(const utility::parameters& params, const std::array<double, 2>& a1, const std::array<double, 2>& a2,
+            const std::vector<std::array<double, 2>>& orbs)
+        : a1_(a1), a2_(a2), orbs_(orbs), L1_(params.getInt("Lattice", "L1")), L2_(params.getInt("Lattice", "L2")), n_orb_((int)orbs.size()) {
+        if (L1_ <= 0 || L2_ <= 0 || n_orb_ == 0) throw std::invalid_argument("Bad lattice dims");
+        const double det = a1_[0] * a2_[1] - a1_[1] * a2_[0];
+        if (std::abs(det) < 1e-12) throw std::invalid_argument("Singular lattice");
+        b1_ = {2 * M_PI * a2_[1] / det / L1_, -2 * M_PI * a2_[0] / det / L1_};
+        b2_ = {-2 * M_PI * a1_[1] / det / L2_, 2 * M_PI * a1_[0] / det / L2_};
+        for (int nn = 0; nn < L1_; ++nn) for (int m = 0; m < L2_; ++m) {
+            const int qx = nn - L1_ / 2 + 1, qy = m - L2_ / 2 + 1;
+            k_points_.push_back({qx * b1_[0] + qy * b2_[0], qx * b1_[1] + qy * b2_[1]});
+        }
+    }
+    int n_cells() const noexcept { return L1_ * L2_; }
+    int n_sites() const noexcept { return L1_ * L2_ * n_orb_; }
+    const int& L1() const noexcept { return L1_; }
+    const int& L2() const noexcept { return L2_; }
+    const int& n_orb() const noexcept { return n_orb_; }
+    const std::array<double, 2>& a1() const noexcept { return a1_; }
+    const std::array<double, 2>& a2() const noexcept { return a2_; }
+    const std::vector<std::array<double, 2>>& k_points() const noexcept { return k_points_; }
+    int site_neighbors(int idx, std::array<int, 2> delta, int orb) const {
+        const int cell = idx / n_orb_, ux = cell % L1_, uy = cell / L1_;
+        const int tx = ((ux + delta[0]) % L1_ + L1_) % L1_, ty = ((uy + delta[1]) % L2_ + L2_) % L2_;
+        return (ty * L1_ + tx) * n_orb_ + orb;
+    }
+    void save_info(const std::string& filename) const {
+        const std::string dir = filename.substr(0, filename.find_last_of("/\\"));
+        if (!dir.empty() && dir != filename) { struct stat info; if (stat(dir.c_str(), &info) != 0) mkdir(dir.c_str(), 0755); }
+        std::ofstream out(filename);
+        if (out.is_open()) out << "L1 " << L1_ << "\nL2 " << L2_ << "\nn_orb " << n_orb_ << "\na1_x " << a1_[0] << "\na1_y " << a1_[1] << "\na2_x " << a2_[0] << "\na2_y " << a2_[1] << "\n";
+    }
+};
+
+// include/field.h:13-84.  fields_ is nt x nv, column-major, 64-bit (arma::imat layout).
+class GHQField {
+    std::array<double, 4> gamma_{}, eta_{};
+    static constexpr int proposal_[4][3] = {{1, 2, 3}, {0, 2, 3}, {0, 1, 3}, {0, 1, 2}};
+    int nt_ = 0, nv_ = 0;
+    std::vector<int64_t> fields_;
+public:
+    GHQField() = default;
+    GHQField(int nt, int nv, utility::random rng /* BY VALUE, as the reference: the caller's generator does not advance */) : nt_(nt), nv_(nv) {
+        const double s6 = std::sqrt(6.0);
+        gamma_ = {1.0 - s6 / 3.0, 1.0 + s6 / 3.0, 1.0 + s6 / 3.0, 1.0 - s6 / 3.0};
+        eta_ = {-std::sqrt(2.0 * (3.0 + s6)), -std::sqrt(2.0 * (3.0 - s6)), std::sqrt(2.0 * (3.0 - s6)), std::sqrt(2.0 * (3.0 + s6))};
+        fields_.resize((size_t)nt * nv);
+        std::uniform_int_distribution<int> dist(0, 3);
+        for (auto& f : fields_) f = dist(rng.get_generator());
+    }
+    double gamma(int f) const { return gamma_[f]; }
+    double eta(int f) const { return eta_[f]; }
+    const std::array<double, 4>& gamma_table() const { return gamma_; }
+    const std::array<double, 4>& eta_table() const { return eta_; }
+    int single_val(int l, int i) const { return (int)fields_[l + (size_t)nt_ * i]; }
+    const std::vector<int64_t>& fields() const { return fields_; }
+    std::vector<int64_t>& fields_mut() { return fields_; }
+    int nv() const { return nv_; }
+    int nt() const { return nt_; }
+    void set_single_field(int l, int i, int v) { fields_[l + (size_t)nt_ * i] = v; }
+    void set_fields(const std::vector<int64_t>& f) { fields_ = f; }
+    static int proposal(int old_field, int k) { return proposal_[old_field][k]; }
+    int propose_new_field(int old_field, utility::random rng /* BY VALUE (include/field.h:76) */) const {
+        std::uniform_int_distribution<int> dist(0, 2);
+        return proposal_[old_field][dist(rng.get_generator())];
+    }
+};
+
+namespace dqmc_detail {
+// exp(A) for a small-norm dense matrix: scaling and squaring with a degree-18 Taylor series
+// (the reference calls arma::expmat, source/model.cpp:32-35; setup only).
+inline std::vector<double> expm(const std::vector<double>& A, int n) {
+    double nrm = 0.0;
+    for (int j = 0; j < n; ++j) { double s = 0.0; for (int i = 0; i < n; ++i) s += std::fabs(A[i + (size_t)n * j]); nrm = std::max(nrm, s); }
+    int sq = 0; while (std::ldexp(nrm, -sq) > 0.25) ++sq;
+    const double sc = std::ldexp(1.0, -sq);
+    std::vector<double> X(A.size()), term((size_t)n * n, 0.0), E((size_t)n * n, 0.0), T((size_t)n * n);
+    for (size_t k = 0; k < A.size(); ++k) X[k] = A[k] * sc;
+    for (int i = 0; i < n; ++i) { term[i + (size_t)n * i] = 1.0; E[i + (size_t)n * i] = 1.0; }
+    auto mul = [n](const std::vector<double>& P, const std::vector<double>& Q, std::vector<double>& R) {
+        std::fill(R.begin(), R.end(), 0.0);
+        for (int j = 0; j < n; ++j) for (int k = 0; k < n; ++k) { const double q = Q[k + (size_t)n * j]; if (q == 0.0) continue; for (int i = 0; i < n; ++i) R[i + (size_t)n * j] += P[i + (size_t)n * k] * q; }
+    };
+    for (int k = 1; k <= 18; ++k) { mul(term, X, T); for (size_t e = 0; e < T.size(); ++e) { term[e] = T[e] / k; E[e] += term[e]; } }
+    for (int s = 0; s < sq; ++s) { mul(E, E, T); E.swap(T); }
+    return E;
+}
+inline void check(int rc) {
+    if (rc == DQMC_OK) return;
+    const std::string msg = dqmc_last_error();
+    if (rc == DQMC_ERANGE) throw std::out_of_range(msg);       // LDRStack::operator[] (include/stackngf.h:61-66)
+    if (rc == DQMC_EINVAL) throw std::invalid_argument(msg);
+    throw std::runtime_error(msg);                             // e.g. "QR decomposition failed in to_LDR" (source/stablelinalg.cpp:43-45)
+}
+}  // namespace dqmc_detail
+
+// include/model.h:11-58
+class AttractiveHubbard {
+    double t_, mu_, g_, alpha_;
+    int ns_, nt_;
+    std::vector<double> expK_, invexpK_, expKhalf_, invexpKhalf_;
+    GHQField fields_;
+    utility::random& rng_;
+    std::vector<double> build_K_matrix(const Lattice& lat) const {           // source/model.cpp:39-60
+        const int n = lat.n_sites(); std::vector<double> K((size_t)n * n, 0.0);
+        for (int i = 0; i < n; ++i) {
+            K[i + (size_t)n * i] = -mu_;
+            const int nx = lat.site_neighbors(i, {1, 0}, 0); K[i + (size_t)n * nx] = -t_; K[nx + (size_t)n * i] = -t_;
+            const int ny = lat.site_neighbors(i, {0, 1}, 0); K[i + (size_t)n * ny] = -t_; K[ny + (size_t)n * i] = -t_;
+        }
+        return K;
+    }
+public:
+    AttractiveHubbard(const utility::parameters& params, const Lattice& lat, utility::random& rng, double replica_beta) : rng_(rng) {
+        t_ = params.getDouble("hubbard", "t"); mu_ = params.getDouble("hubbard", "mu");
+        ns_ = lat.n_cells(); nt_ = (int)params.getDouble("simulation", "nt");
+        const double U = params.getDouble("hubbard", "U"), dtau = replica_beta / nt_;
+        fields_ = GHQField(nt_, ns_, rng);
+        g_ = std::sqrt(0.5 * std::abs(U) * dtau); alpha_ = -1.0;
+        std::vector<double> K = build_K_matrix(lat), S(K.size());
+        auto scaled = [&](double f) { for (size_t k = 0; k < K.size(); ++k) S[k] = f * K[k]; return dqmc_detail::expm(S, ns_); };
+        expK_ = scaled(-dtau); invexpK_ = scaled(dtau); expKhalf_ = scaled(-0.5 * dtau); invexpKhalf_ = scaled(0.5 * dtau);
+    }
+    const std::vector<double>& expK(int) const { return expK_; }
+    const std::vector<double>& invexpK(int) const { return invexpK_; }
+    const std::vector<double>& expK_half(int) const { return expKhalf_; }
+    const std::vector<double>& invexpK_half(int) const { return invexpKhalf_; }
+    std::vector<double> expV(int l, int) const { std::vector<double> v(ns_); for (int i = 0; i < ns_; ++i) v[i] = std::exp(g_ * fields_.eta(fields_.single_val(l, i))); return v; }
+    std::vector<double> invexpV(int l, int) const { std::vector<double> v(ns_); for (int i = 0; i < ns_; ++i) v[i] = std::exp(-g_ * fields_.eta(fields_.single_val(l, i))); return v; }
+    GHQField& fields() { return fields_; }
+    const GHQField& fields() const { return fields_; }
+    int nt() const { return nt_; }
+    int ns() const { return ns_; }
+    int n_flavor() const { return 1; }
+    double g() const { return g_; }
+    double alpha() const { return alpha_; }
+    utility::random& rng() { return rng_; }
+    // source/model.cpp:99-107
+    std::pair<double, double> bosonic_ratio(int new_field, int old_field) const {
+        const double d_eta = fields_.eta(new_field) - fields_.eta(old_field);
+        const double br = std::exp(alpha_ * g_ * d_eta);
+        return {br, (1.0 / br) - 1.0};
+    }
+};
+
+// include/stackngf.h:15-29: the equal-time members; matrices are downloaded on demand.
+struct GF {
+    std::vector<double> Gtt0;     // host copy of Gtt[0] (column-major ns x ns), refreshed by DQMC::download
+    double log_det_M = 0.0;
+};
+
+class DQMC;
+// include/stackngf.h:34-77: a handle; the LDR triples live in HBM inside the engine.
+class LDRStack {
+    friend class DQMC;
+    dqmc_engine* e_ = nullptr; size_t n_stack_ = 0; int n_ = 0;
+public:
+    LDRStack() = default;
+    LDRStack(LDRStack&&) noexcept = default;
+    LDRStack& operator=(LDRStack&&) noexcept = default;
+    LDRStack(const LDRStack&) = delete;
+    LDRStack& operator=(const LDRStack&) = delete;
+    constexpr size_t size() const noexcept { return n_stack_; }
+    struct LDR { std::vector<double> L, d, R; };
+    LDR operator[](size_t idx) const {
+        if (idx >= n_stack_) throw std::out_of_range("LDR Stack index out of bounds");
+        LDR f; f.L.resize((size_t)n_ * n_); f.d.resize(n_); f.R.resize((size_t)n_ * n_);
+        dqmc_detail::check(dqmc_get_stack(e_, (int)idx, f.L.data(), f.d.data(), f.R.data()));
+        return f;
+    }
+};
+
+namespace update {
+// The random stream update::local_update consumes for ONE time slice
+// (source/update.cpp:10-25), drawn with the reference's own calls in the reference's order:
+// std::shuffle of the site order; then per site a proposal index from a BY-VALUE COPY of the
+// generator (include/field.h:76-83 -- the shared generator does not advance) and the canonical
+// uniform of bernoulli(p) (include/utility.h:34-37), which advances it by exactly two words
+// whatever p is.  The copy is replayed from the two words the bernoulli draw is about to consume.
+struct ReplayURNG {
+    using result_type = std::mt19937::result_type;
+    static constexpr result_type min() { return std::mt19937::min(); }
+    static constexpr result_type max() { return std::mt19937::max(); }
+    result_type w[2]; int k = 0; const std::mt19937* after;     // `after`: generator state once w[0], w[1] are consumed
+    std::mt19937 tail; bool tail_init = false;
+    result_type operator()() {
+        if (k < 2) return w[k++];
+        if (!tail_init) { tail = *after; tail_init = true; }    // Lemire rejection ran past two words (p ~ 2^-32): fall back to a real copy
+        return tail();
+    }
+};
+inline void draw_slice_stream(utility::random& rng, int nv, int32_t* perm, uint8_t* kprop, double* u) {
+    std::vector<int> field_order(nv);
+    for (int i = 0; i < nv; ++i) field_order[i] = i;
+    std::shuffle(field_order.begin(), field_order.end(), rng.get_generator());      // source/update.cpp:14
+    std::mt19937& gen = rng.get_generator();
+    for (int idx = 0; idx < nv; ++idx) {
+        perm[idx] = field_order[idx];
+        ReplayURNG rep; rep.w[0] = gen(); rep.w[1] = gen(); rep.after = &gen;
+        std::uniform_int_distribution<int> dist(0, 2);                             // include/field.h:79
+        kprop[idx] = (uint8_t)dist(rep);
+        // std::generate_canonical<double, 53>(mt19937): (w0 + w1 * 2^32) / 2^64, what bernoulli_distribution compares with p
+        double c = (static_cast<double>(rep.w[0]) + static_cast<double>(rep.w[1]) * 4294967296.0) / 18446744073709551616.0;
+        if (c >= 1.0) c = std::nextafter(1.0, 0.0);
+        u[idx] = c;
+    }
+}
+// source/update.cpp:34-45
+inline int partner_rank(const int rank, const int world_size, const int exchange_attempt) {
+    const bool even_attempt = (exchange_attempt % 2 == 0);
+    const int off = even_attempt ? ((rank % 2 == 0) ? 1 : -1) : ((rank % 2 == 0) ? -1 : 1);
+    return (rank + off + world_size) % world_size;
+}
+}  // namespace update
+
+// include/dqmc.h:21-93
+class DQMC {
+    AttractiveHubbard& model_;
+    dqmc_engine* e_ = nullptr;
+    int nt_, n_stab_, n_stack_;
+    std::vector<int32_t> perm_; std::vector<uint8_t> kprop_; std::vector<double> u_;
+    void draw_half_sweep(bool forward) {
+        const int ns = model_.ns();
+        for (int step = 0; step < nt_; ++step) {
+            const int l = forward ? step : nt_ - 1 - step;       // slices in the order the sweep visits them
+            update::draw_slice_stream(model_.rng(), ns, perm_.data() + (size_t)l * ns, kprop_.data() + (size_t)l * ns, u_.data() + (size_t)l * ns);
+        }
+    }
+public:
+    DQMC(const utility::parameters& params, AttractiveHubbard& model, int device = 0) : model_(model) {
+        nt_ = params.getInt("simulation", "nt"); n_stab_ = params.getInt("simulation", "n_stab");
+        n_stack_ = (int)std::ceil(static_cast<double>(nt_) / n_stab_);
+        const GHQField& f = model.fields();
+        dqmc_detail::check(dqmc_create(&e_, device, model.ns(), nt_, n_stab_, model.g(), f.gamma_table().data(), f.eta_table().data(),
+                                       model.expK(0).data(), model.invexpK(0).data()));
+        const size_t cnt = (size_t)nt_ * model.ns(); perm_.resize(cnt); kprop_.resize(cnt); u_.resize(cnt);
+    }
+    ~DQMC() { dqmc_destroy(e_); }
+    DQMC(const DQMC&) = delete;
+    DQMC& operator=(const DQMC&) = delete;
+    dqmc_engine* handle() { return e_; }
+    double acc_rate() { dqmc_stats s; dqmc_detail::check(dqmc_get_stats(e_, &s)); return s.acc_rate; }
+    double max_err() { dqmc_stats s; dqmc_detail::check(dqmc_get_stats(e_, &s)); return s.max_err; }
+    double mean_err() { dqmc_stats s; dqmc_detail::check(dqmc_get_stats(e_, &s)); return s.sum_err / s.n_err; }
+    // source/dqmc.cpp:43-59: uploads the model's fields and rebuilds every stack[i] = B(beta, tau_i)
+    LDRStack init_stacks(int /*flv*/) {
+        dqmc_detail::check(dqmc_set_fields(e_, model_.fields().fields().data()));
+        dqmc_detail::check(dqmc_init(e_));
+        LDRStack s; s.e_ = e_; s.n_stack_ = (size_t)n_stack_; s.n_ = model_.ns(); return s;
+    }
+    // source/dqmc.cpp:61-72
+    GF init_greenfunctions(LDRStack&) { GF g; download(g); return g; }
+    void download(GF& g) {
+        g.Gtt0.resize((size_t)model_.ns() * model_.ns());
+        dqmc_detail::check(dqmc_get_G(e_, g.Gtt0.data()));
+        dqmc_detail::check(dqmc_get_logdet(e_, &g.log_det_M));
+    }
+    // pulls the device's HS fields back into model.fields() (they change on device during sweeps)
+    void download_fields() { dqmc_detail::check(dqmc_get_fields(e_, model_.fields().fields_mut().data())); }
+    // source/dqmc.cpp:337-396 / :398-456; asynchronous, greens are refreshed by download()
+    void sweep_0_to_beta(std::vector<GF>&, std::vector<LDRStack>&) { draw_half_sweep(true); dqmc_detail::check(dqmc_sweep_0_to_beta(e_, perm_.data(), kprop_.data(), u_.data())); }
+    void sweep_beta_to_0(std::vector<GF>&, std::vector<LDRStack>&) { draw_half_sweep(false); dqmc_detail::check(dqmc_sweep_beta_to_0(e_, perm_.data(), kprop_.data(), u_.data())); }
+    void sweep_unequalTime(std::vector<GF>&, std::vector<LDRStack>&) {}          // out of scope; no-op as with isMeasureUnequalTime=false (source/dqmc.cpp:461-463)
+    double global_action() { double S; dqmc_detail::check(dqmc_global_action(e_, &S)); return S; }   // source/model.cpp:140-159
+};
+
+namespace update {
+// source/update.cpp:47-117.  The MPI_Sendrecv / MPI_Send / MPI_Recv calls of the reference are
+// supplied by the caller as three std::functions so the same code runs over RCCL (one rank per
+// GPU, dqmc_amd/replica.py does the transport with torch.distributed's "nccl" = RCCL backend),
+// over MPI, or in-process for tests.
+struct Transport {
+    std::function<void(const int64_t* send, int64_t* recv, size_t count, int partner)> sendrecv_fields;   // tag 0
+    std::function<double(double mine, int partner, int tag)> sendrecv_double;                              // tags 1, 2
+    std::function<bool(bool value, int partner, bool i_decide)> share_decision;                            // tag 3
+};
+inline void replica_exchange(int rank, int world_size, utility::random& rng, int& exchange_attempt, int& exchange_accepted,
+                             AttractiveHubbard& model, DQMC& sim, std::vector<GF>& greens, std::vector<LDRStack>& stacks, const Transport& tr) {
+    exchange_attempt++;
+    const int partner = partner_rank(rank, world_size, exchange_attempt);
+    if (partner < 0 || partner >= world_size) return;
+    sim.download_fields();
+    const std::vector<int64_t> my_fields = model.fields().fields();
+    std::vector<int64_t> partner_fields(my_fields.size());
+    tr.sendrecv_fields(my_fields.data(), partner_fields.data(), my_fields.size(), partner);
+    const double SC = sim.global_action();                                   // S_r({s}_r)
+    model.fields().set_fields(partner_fields);
+    for (int flv = 0; flv < model.n_flavor(); ++flv) { stacks[flv] = sim.init_stacks(flv); greens[flv] = sim.init_greenfunctions(stacks[flv]); }
+    const double SC_prime = sim.global_action();                             // S_r({s}_partner)
+    const double SC_prime_partner = tr.sendrecv_double(SC_prime, partner, 1);
+    const double SC_partner = tr.sendrecv_double(SC, partner, 2);
+    bool accept = false;
+    if (rank < partner) {
+        const double deltaS = (SC_prime + SC_prime_partner) - (SC + SC_partner);
+        accept = rng.bernoulli(std::min(1.0, std::exp(-deltaS)));
+        if (rank == 0) exchange_accepted += accept;
+        accept = tr.share_decision(accept, partner, true);
+    } else accept = tr.share_decision(false, partner, false);
+    if (!accept) {
+        model.fields().set_fields(my_fields);
+        for (int flv = 0; flv < model.n_flavor(); ++flv) { stacks[flv] = sim.init_stacks(flv); greens[flv] = sim.init_greenfunctions(stacks[flv]); }
+    }
+}
+}  // namespace update

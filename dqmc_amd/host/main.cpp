@@ -1,0 +1,67 @@
+// main.cpp -- a driver with the loop shape of the reference's source/main.cpp:14-214 on top of the
+// host facade: read ./parameters.in (or argv[1]), build Lattice / AttractiveHubbard / DQMC,
+// thermalise, sweep, report time, acceptance and wrap error.  One process = one Markov chain on one
+// GPU (the reference's MPI rank); the multi-GPU launcher and replica exchange over RCCL are in
+// bench.py / dqmc_amd/replica.py.  Measurements (Observables, HDF5) are out of scope.
+#include "dqmc_host.hpp"
+
+#include <chrono>
+#include <cstdio>
+#include <ctime>
+#include <iomanip>
+#include <iostream>
+
+int main(int argc, char** argv) {
+    try {
+        const std::string pfile = argc > 1 ? argv[1] : "parameters.in";
+        const int device = argc > 2 ? std::atoi(argv[2]) : 0;
+        const unsigned seed = argc > 3 ? (unsigned)std::strtoul(argv[3], nullptr, 10) : (unsigned)std::time(nullptr);   // source/main.cpp:37
+        utility::parameters params(pfile);
+        utility::random rng(seed);
+        const double my_beta = params.getDouble("simulation", "beta");
+        const int n_sweeps = params.getInt("simulation", "n_sweeps"), n_therms = params.getInt("simulation", "n_therms"), n_bins = params.getInt("simulation", "n_bins");
+
+        Lattice lat(params, {1.0, 0.0}, {0.0, 1.0}, {{0.0, 0.0}});
+        lat.save_info("results/info");
+        AttractiveHubbard model(params, lat, rng, my_beta);
+        const int n_flavor = model.n_flavor();
+        DQMC sim(params, model, device);
+
+        std::vector<LDRStack> propagation_stacks(n_flavor);
+        std::vector<GF> greens(n_flavor);
+        for (int flv = 0; flv < n_flavor; flv++) {
+            propagation_stacks[flv] = sim.init_stacks(flv);
+            greens[flv] = sim.init_greenfunctions(propagation_stacks[flv]);
+        }
+        std::cout << "Standard DQMC run (Parallel Tempering disabled), backend " << dqmc_backend() << ", log det M = "
+                  << std::setprecision(12) << greens[0].log_det_M << "\n";
+
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int i = 0; i < n_therms; ++i) { sim.sweep_0_to_beta(greens, propagation_stacks); sim.sweep_beta_to_0(greens, propagation_stacks); }
+        sim.download(greens[0]);
+        const double dt_therm = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        std::cout << "Thermalization done in " << dt_therm << " seconds\n";
+
+        const long bin_sweeps = (long)n_bins * n_sweeps;
+        const auto t1 = std::chrono::steady_clock::now();
+        for (long isweep = 1; isweep <= bin_sweeps; ++isweep) {
+            sim.sweep_0_to_beta(greens, propagation_stacks);
+            sim.sweep_beta_to_0(greens, propagation_stacks);
+            sim.sweep_unequalTime(greens, propagation_stacks);
+            if (isweep % n_sweeps == 0) sim.download(greens[0]);      // where measurements.accumulate would read Gtt[0]
+        }
+        sim.download(greens[0]);
+        const double local_time = std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
+        const double acc = sim.acc_rate() / (n_bins * 2.0 * n_sweeps + 2.0 * n_therms);     // source/main.cpp:183
+        const int total_sec = (int)local_time;
+        std::cout << "DQMC measurement sweeps are finished in " << total_sec / 3600 << " hours " << (total_sec % 3600) / 60 << " minutes "
+                  << total_sec % 60 << " seconds.\n"
+                  << "Average acceptance rate = " << std::fixed << std::setprecision(4) << acc << '\n'
+                  << "Max, Mean Precision Error = " << std::scientific << std::setprecision(4) << sim.max_err() << ", " << sim.mean_err() << '\n'
+                  << "sweeps/s = " << std::fixed << std::setprecision(3) << (bin_sweeps > 0 ? bin_sweeps / local_time : 0.0) << '\n';
+        return 0;
+    } catch (const std::exception& e) {
+        std::cerr << "dqmc_driver: " << e.what() << std::endl;
+        return 1;
+    }
+}
