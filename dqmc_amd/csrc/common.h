@@ -96,7 +96,9 @@ int launch_to_ldr(Mat A, Mat L, Vec d, Mat R, QrWork w, int n, int n_chains, hip
 // In-place LU with partial pivoting of A[c] (P A = L U); perm (n ints per
 // chain): row r of P*A is row perm[r] of A.  logabsdet[c] (+)= sum log|u_ii|
 // when non-null.  *info |= 1 on a zero / NaN pivot.
-int launch_lu(Mat A, int* perm, long perm_stride, double* logabsdet, int accumulate_logdet, int* info, int n, int n_chains, hipStream_t s);
+// rowpos: scratch of n ints per chain for the blocked path (null -> single-workgroup streaming kernel)
+int launch_lu(Mat A, int* perm, long perm_stride, double* logabsdet, int accumulate_logdet, int* info, int n, int n_chains, hipStream_t s,
+              int* rowpos = nullptr, long rowpos_stride = 0);
 // Solve A X = B with the factors above, n right-hand sides.
 //   mode 0: X holds B on entry, overwritten by the solution.
 //   mode 1: B = diag(dg); X is overwritten.

@@ -46,14 +46,15 @@ struct Ctx {
     static constexpr int NT = 10;              // workspace matrices
     double* pool = nullptr;                    // NT * C * nn
     double* vpool = nullptr;                   // vectors: 8 * C * n
-    int* ipool = nullptr;                      // 2 * C * n ints + info
+    int* ipool = nullptr;                      // 3 * C * n ints + info
     double* spool = nullptr;                   // scalars: 4 * C
 
     Mat T(int k) const { return Mat{pool + (long)k * C * nn, nn}; }
     Vec V(int k) const { return Vec{vpool + (long)k * C * n, (long)n}; }
     int* jpvt() const { return ipool; }
     int* lperm() const { return ipool + (long)C * n; }
-    int* info() const { return ipool + 2L * C * n; }
+    int* rowpos() const { return ipool + 2L * C * n; }
+    int* info() const { return ipool + 3L * C * n; }
     double* logsum() const { return spool; }           // C
     double* scal(int k) const { return spool + (long)k * C; }
 
@@ -63,9 +64,9 @@ struct Ctx {
         DQ_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         DQ_HIP(hipMalloc(&pool, sizeof(double) * NT * C * nn));
         DQ_HIP(hipMalloc(&vpool, sizeof(double) * 8 * C * n));
-        DQ_HIP(hipMalloc(&ipool, sizeof(int) * (2L * C * n + 4)));
+        DQ_HIP(hipMalloc(&ipool, sizeof(int) * (3L * C * n + 4)));
         DQ_HIP(hipMalloc(&spool, sizeof(double) * 4 * C));
-        DQ_HIP(hipMemsetAsync(ipool, 0, sizeof(int) * (2L * C * n + 4), stream));
+        DQ_HIP(hipMemsetAsync(ipool, 0, sizeof(int) * (3L * C * n + 4), stream));
         return 0;
     }
     ~Ctx() {
@@ -93,7 +94,7 @@ struct Ctx {
     int r_inverse_scaled(LdrRef F, CVec dinv, Mat X, Mat lu_scratch) {
         if (F.tri && *F.tri && F.jpvt) return launch_lu_solve(F.R, F.jpvt, n, X, dinv, 2, n, C, stream);
         DQ_TRY(launch_copy(F.R, lu_scratch, nn, C, stream));
-        DQ_TRY(launch_lu(lu_scratch, lperm(), n, nullptr, 0, info(), n, C, stream));
+        DQ_TRY(launch_lu(lu_scratch, lperm(), n, nullptr, 0, info(), n, C, stream, rowpos(), n));
         return launch_lu_solve(lu_scratch, lperm(), n, X, dinv, 1, n, C, stream);
     }
     // stablelinalg::mat_mul_ldr (source/stablelinalg.cpp:69-79): out = M * F   (uses T0,T1)
@@ -128,7 +129,7 @@ struct Ctx {
         DQ_TRY(r_inverse_scaled(F, V(0), T(1), T(0)));                                  // X = R^-1 diag(1/Dl)
         DQ_TRY(launch_add_scaled_cols(T(1), F.L, V(1), T(2), n, C, stream));            // M = X + L diag(Ds)
         DQ_TRY(launch_transpose_scale(T(2), T(3), CVec(), n, C, stream));               // M^T
-        DQ_TRY(launch_lu(T(3), lperm(), n, logdet, 1, info(), n, C, stream));           // logdet += log|det M|
+        DQ_TRY(launch_lu(T(3), lperm(), n, logdet, 1, info(), n, C, stream, rowpos(), n));           // logdet += log|det M|
         DQ_TRY(launch_transpose_scale(T(1), T(4), CVec(), n, C, stream));               // X^T
         DQ_TRY(launch_lu_solve(T(3), lperm(), n, T(4), CVec(), 0, n, C, stream));       // G^T
         return launch_transpose_scale(T(4), G, CVec(), n, C, stream);
@@ -141,7 +142,7 @@ struct Ctx {
         DQ_TRY(gemm(F1.L, T(1), T(2), V(0), CVec(), CVec(), 1));                        // TermA = diag(1/D1l) L1^T X
         DQ_TRY(gemm(F1.R, F2.L, T(2), V(1), CVec(), V(3), 0, 1));                       // M = TermA + diag(D1s) R1 L2 diag(D2s)
         DQ_TRY(launch_transpose_scale(F1.L, T(3), V(0), n, C, stream));                 // RHS = diag(1/D1l) L1^T
-        DQ_TRY(launch_lu(T(2), lperm(), n, nullptr, 0, info(), n, C, stream));
+        DQ_TRY(launch_lu(T(2), lperm(), n, nullptr, 0, info(), n, C, stream, rowpos(), n));
         DQ_TRY(launch_lu_solve(T(2), lperm(), n, T(3), CVec(), 0, n, C, stream));       // Y = M^-1 RHS
         return gemm(T(1), T(3), G);                                                     // G = X Y
     }

@@ -22,6 +22,7 @@
 //                    substitutions with the pivot element broadcast by a lane
 //                    shuffle: no LDS, no barriers.
 #include "common.h"
+#include <cstdlib>
 
 namespace dq {
 
@@ -208,8 +209,14 @@ static int launch_lu_nr(Mat A, int* perm, long ps, double* lad, int acc, int* in
     DQ_HIP(hipGetLastError());
     return 0;
 }
-int launch_lu(Mat A, int* perm, long perm_stride, double* logabsdet, int accumulate_logdet, int* info, int n, int n_chains, hipStream_t s) {
+int launch_lu_blocked(Mat A, int* perm, long perm_stride, int* rowpos, long rowpos_stride, double* logabsdet, int accumulate_logdet,
+                      int* info, int n, int n_chains, hipStream_t s);     // lu_blocked.hip
+
+int launch_lu(Mat A, int* perm, long perm_stride, double* logabsdet, int accumulate_logdet, int* info, int n, int n_chains, hipStream_t s,
+              int* rowpos, long rowpos_stride) {
     if (n > 1024) { set_error("LU kernel supports n <= 1024"); return -1; }
+    static const bool force_stream = getenv("DQMC_LU_STREAMING") != nullptr;    // A/B switch for tests and profiling
+    if (rowpos && !force_stream) return launch_lu_blocked(A, perm, perm_stride, rowpos, rowpos_stride, logabsdet, accumulate_logdet, info, n, n_chains, s);
     if (n <= 64) return launch_lu_nr<1>(A, perm, perm_stride, logabsdet, accumulate_logdet, info, n, n_chains, s);
     if (n <= 128) return launch_lu_nr<2>(A, perm, perm_stride, logabsdet, accumulate_logdet, info, n, n_chains, s);
     if (n <= 256) return launch_lu_nr<4>(A, perm, perm_stride, logabsdet, accumulate_logdet, info, n, n_chains, s);
