@@ -50,7 +50,8 @@ struct OcShared {
     double* vn1;                  // [256]
     double* vn2;                  // [256]
     unsigned long long* keys;     // [8]
-    double* scal;                 // [0] = |x(i+1:)|^2
+    double* scal;                 // [0] = tau, [1] = beta, [2] = 1/(alpha-beta) of the current step
+    double* rowi;                 // [256] row i of every column (norm down-date)
     int* pposl;                   // [256] pivot position of a pivoted column
 };
 
@@ -85,18 +86,26 @@ __device__ __forceinline__ void qr_block(double (&a)[OC_KR][16], int& livem, con
                 if (r > i) ss += x * x;
             }
             ss = row16_sum(ss);                // every DPP row sums its own lanes; only the pivot's row is used
-            if (mine && rg == 0) sh.scal[0] = ss;
+            // dlarfg scalars, computed once here (sqrt and two divisions cost ~0.4 us when all 8 waves repeat them)
+            const int r_i = i & 15;            // lane of the pivot row that holds row i (slot JB)
+            double al_l = 0.0;
+#pragma unroll
+            for (int kc = 0; kc < OC_KR; ++kc) if (kcp == kc) al_l = a[kc][JB];
+            if (kcp == 6) al_l = LCOL(6, JB);
+            if (kcp == 7) al_l = LCOL(7, JB);
+            if (mine && rg == r_i) {
+                double tau_l = 0.0, beta_l = al_l, scale_l = 0.0;
+                if (ss != 0.0) {
+                    beta_l = -copysign(sqrt(al_l * al_l + ss), al_l);
+                    tau_l = (beta_l - al_l) / beta_l;
+                    scale_l = 1.0 / (al_l - beta_l);
+                }
+                sh.scal[0] = tau_l; sh.scal[1] = beta_l; sh.scal[2] = scale_l;
+            }
         }
         __syncthreads();
         // ---- [B] Householder vector (dlarfg) ----
-        const double al = sh.xbuf[i];
-        const double xnorm2 = sh.scal[0];
-        double tau_i = 0.0, beta = al, scale = 0.0;
-        if (xnorm2 != 0.0) {
-            beta = -copysign(sqrt(al * al + xnorm2), al);
-            tau_i = (beta - al) / beta;
-            scale = 1.0 / (al - beta);
-        }
+        const double tau_i = sh.scal[0], beta = sh.scal[1], scale = sh.scal[2];
         if (t < OC_N && t >= 16 * JB) {
             const int r = t;
             double vr = 0.0;
@@ -137,31 +146,42 @@ __device__ __forceinline__ void qr_block(double (&a)[OC_KR][16], int& livem, con
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        // ---- norm down-date (dlaqp2) by the lanes that hold row i (register a[kc][JB]), new keys ----
-        // Pass 1 finds the columns whose norm must be recomputed (cancellation), the rare pass 2
-        // recomputes them cooperatively, pass 3 applies the down-date and forms the pivot keys.
-        // One column at a time: nothing may be kept per column, the register file is full.
-        const bool own_row = rg == (i & 15);
-        int need = 0;
-        if (own_row) {
+        // ---- norm down-date (dlaqp2), new keys ----
+        // The lanes that hold row i (rg == i & 15, register a[kc][JB]) drop their 8 row-i entries in LDS;
+        // then lane q < 32 of every wave owns column 32*wave + q and runs ONE divide/sqrt chain
+        // (eight sequential chains in four lanes cost > 1 us per step).  A column whose norm must be
+        // recomputed (cancellation) is flagged and handled cooperatively by its 16 row-group lanes (rare).
+        if (rg == (i & 15)) {
 #pragma unroll
-            for (int kc = 0; kc < OC_KC; ++kc) {
-                if (livem & (1 << kc)) {
-                    const double rv = kc < OC_KR ? a[kc < OC_KR ? kc : 0][JB] : LCOL(kc, JB);
-                    const double n1_ = sh.vn1[cbase + kc];
-                    if (n1_ != 0.0) {
-                        double temp = fabs(rv) / n1_; temp = fmax(0.0, 1.0 - temp * temp);
-                        const double rr = n1_ / sh.vn2[cbase + kc];
-                        if (temp * rr * rr <= tol3z) need |= 1 << kc;
-                    }
-                }
+            for (int kc = 0; kc < OC_KC; ++kc) sh.rowi[cbase + kc] = kc < OC_KR ? a[kc < OC_KR ? kc : 0][JB] : LCOL(kc, JB);
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);                    // lgkmcnt(0): my wave's LDS writes are done (wave-local hand-off)
+        __builtin_amdgcn_wave_barrier();
+        int need = 0;                                          // bit kc (of MY columns) -> recompute
+        double nn = 0.0; bool col_live = false; int need_col = 0;
+        const int mycol = 32 * wave + (lane & 31);
+        {
+            // liveness of column mycol: its owner lanes are 16*(q >> 3) + any rg (q = lane & 31), bit q & 7 of their livem
+            const int lm = __shfl(livem, ((lane & 31) >> 3) << 4, 64);
+            col_live = lane < 32 && ((lm >> (lane & 7)) & 1);
+        }
+        if (lane < 32 && col_live) {
+            const double rv = sh.rowi[mycol];
+            const double n1_ = sh.vn1[mycol];
+            nn = n1_;
+            if (n1_ != 0.0) {
+                double temp = fabs(rv) / n1_; temp = fmax(0.0, 1.0 - temp * temp);
+                const double rr = n1_ / sh.vn2[mycol];
+                if (temp * rr * rr <= tol3z) need_col = 1;
+                else { nn = n1_ * sqrt(temp); sh.vn1[mycol] = nn; }
             }
         }
-        need = __shfl(need, (lane & 48) | (i & 15), 64);      // share with the other 15 lanes of the DPP row
-        if (__any(need != 0)) {
+        const unsigned long long needmask = __ballot(need_col);   // bit q: column 32*wave + q needs a recompute
+        if (needmask != 0ULL) {
+            need = (int)((needmask >> (8 * cl)) & 0xFFULL);        // my thread's 8 columns are q = 8*cl .. 8*cl+7
 #pragma unroll
             for (int kc = 0; kc < OC_KC; ++kc) {
-                if (__any((need >> kc) & 1)) {
+                if ((needmask >> kc) & 0x01010101ULL) {            // some DPP row of this wave needs column slot kc
                     double tl = 0.0;
 #pragma unroll
                     for (int j = 0; j < NJ; ++j) {
@@ -171,30 +191,18 @@ __device__ __forceinline__ void qr_block(double (&a)[OC_KR][16], int& livem, con
                         }
                     }
                     tl = row16_sum(tl);
-                    if (own_row && ((need >> kc) & 1)) {
-                        const double nn = (i + 1 < n) ? sqrt(tl) : 0.0;
-                        sh.vn1[cbase + kc] = nn; sh.vn2[cbase + kc] = nn;
+                    if (rg == 0 && ((need >> kc) & 1)) {
+                        const double v2 = (i + 1 < n) ? sqrt(tl) : 0.0;
+                        sh.vn1[cbase + kc] = v2; sh.vn2[cbase + kc] = v2;
                     }
                 }
             }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+            if (lane < 32 && need_col) nn = sh.vn1[mycol];
         }
         {
-            unsigned long long key = 0;
-            if (own_row) {
-#pragma unroll
-                for (int kc = 0; kc < OC_KC; ++kc) {
-                    if (livem & (1 << kc)) {
-                        double nn = sh.vn1[cbase + kc];
-                        if (nn != 0.0 && !((need >> kc) & 1)) {
-                            const double rv = kc < OC_KR ? a[kc < OC_KR ? kc : 0][JB] : LCOL(kc, JB);
-                            double temp = fabs(rv) / nn; temp = fmax(0.0, 1.0 - temp * temp);
-                            nn = nn * sqrt(temp);
-                            sh.vn1[cbase + kc] = nn;
-                        }
-                        const unsigned long long k = norm_key(nn, cbase + kc); key = k > key ? k : key;
-                    }
-                }
-            }
+            unsigned long long key = (lane < 32 && col_live) ? norm_key(nn, mycol) : 0ULL;
             key = wave_max_u64(key);
             if (lane == 0) sh.keys[wave] = key;
         }
@@ -227,7 +235,8 @@ __global__ __launch_bounds__(OC_T) void qrcp_onchip_kernel(Mat Am, QrWork w, int
     sh.vn2 = sh.vn1 + OC_N;
     sh.keys = reinterpret_cast<unsigned long long*>(sh.vn2 + OC_N);
     sh.scal = reinterpret_cast<double*>(sh.keys + 8);
-    sh.pposl = reinterpret_cast<int*>(sh.scal + 8);
+    sh.rowi = sh.scal + 8;
+    sh.pposl = reinterpret_cast<int*>(sh.rowi + OC_N);
 
     const int chain = blockIdx.y;
     double* __restrict__ A = Am.at(chain);
@@ -281,7 +290,7 @@ __global__ __launch_bounds__(OC_T) void qrcp_onchip_kernel(Mat Am, QrWork w, int
 
 int launch_qrcp_onchip(Mat A, QrWork w, int n, int n_chains, hipStream_t s) {
     if (n > OC_N) { set_error("on-chip QRCP supports n <= 256"); return -1; }
-    const size_t lds = sizeof(double) * (2 * 16 * OC_T + 4 * OC_N + 8 + 8) + sizeof(int) * OC_N + 64;
+    const size_t lds = sizeof(double) * (2 * 16 * OC_T + 5 * OC_N + 8 + 8) + sizeof(int) * OC_N + 64;
     static bool attr_set = false;
     if (!attr_set) {
         DQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(qrcp_onchip_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
