@@ -125,6 +125,7 @@ struct UpdateDesc {
     const int32_t* perm; const uint8_t* kprop; const double* u; long rs_stride;  // random stream [chain][nt][n]
     double* Upanel; double* Wpanel; long panel_stride;   // [chain][KD][n]
     int* state; long state_stride;            // per chain: [0]=pos, [1]=k (accepts in current window), [2]=accepted in slice
+    double* prep; long prep_stride;           // per chain 4*n doubles: the slice's G-independent proposal data
     int* acc_out; long acc_stride;            // per chain per slice accepted counts [chain][2*nt] (+ offset chosen by caller)
     int n, nt;
 };

@@ -175,6 +175,7 @@ struct Engine {
     hipEvent_t stage_free = nullptr;
     double* Upanel = nullptr; double* Wpanel = nullptr;          // [C][KD][n]
     int* state = nullptr;                                        // [C][4]
+    double* prep = nullptr;                                      // [C][4n]
     int* acc = nullptr;                                          // [C][nt]
     double* err = nullptr;                                       // [C][n_stack]
     DevStats* dstats = nullptr;                                  // [C]
@@ -200,7 +201,7 @@ struct Engine {
         if (s) (void)hipStreamSynchronize(s);
         for (auto& p : ev_pairs) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
         if (stage_free) (void)hipEventDestroy(stage_free);
-        void* ptrs[] = {stackP, expK, invexpK, fields, expv, invexpv, tabs, tab8, G, Gtmp, bb0, bb1, stackL, stackD, stackR, tmpL, tmpD, tmpR,
+        void* ptrs[] = {prep, stackP, expK, invexpK, fields, expv, invexpv, tabs, tab8, G, Gtmp, bb0, bb1, stackL, stackD, stackR, tmpL, tmpD, tmpR,
                         logdet, rs_perm, rs_k, rs_u, Upanel, Wpanel, state, acc, err, dstats, r1scratch};
         for (void* p : ptrs) if (p) (void)hipFree(p);
         if (h_stage) (void)hipHostFree(h_stage);
@@ -226,7 +227,7 @@ struct Engine {
         DQ_TRY(dalloc(&logdet, C));
         DQ_TRY(dalloc(&rs_perm, (size_t)C * nt * n)); DQ_TRY(dalloc(&rs_k, (size_t)C * nt * n)); DQ_TRY(dalloc(&rs_u, (size_t)C * nt * n));
         DQ_TRY(dalloc(&Upanel, (size_t)C * UPDATE_KD * n)); DQ_TRY(dalloc(&Wpanel, (size_t)C * UPDATE_KD * n));
-        DQ_TRY(dalloc(&state, (size_t)C * 4)); DQ_TRY(dalloc(&acc, (size_t)C * nt)); DQ_TRY(dalloc(&err, (size_t)C * n_stack));
+        DQ_TRY(dalloc(&state, (size_t)C * 4)); DQ_TRY(dalloc(&prep, (size_t)C * 4 * n)); DQ_TRY(dalloc(&acc, (size_t)C * nt)); DQ_TRY(dalloc(&err, (size_t)C * n_stack));
         DQ_TRY(dalloc(&dstats, C)); DQ_TRY(dalloc(&r1scratch, (size_t)C * (2 * n + 1)));
         h_stage_bytes = (size_t)C * nt * n * (sizeof(int32_t) + sizeof(uint8_t) + sizeof(double));
         DQ_HIP(hipHostMalloc(&h_stage, h_stage_bytes, hipHostMallocDefault));
@@ -297,7 +298,7 @@ struct Engine {
     UpdateDesc udesc() const {
         UpdateDesc d; d.G = mG(); d.fields = fields; d.f_stride = (long)nt * n; d.expv = expv; d.invexpv = invexpv; d.v_stride = (long)nt * n;
         d.tabs = tabs; d.perm = rs_perm; d.kprop = rs_k; d.u = rs_u; d.rs_stride = (long)nt * n; d.Upanel = Upanel; d.Wpanel = Wpanel;
-        d.panel_stride = (long)UPDATE_KD * n; d.state = state; d.state_stride = 4; d.acc_out = acc; d.acc_stride = nt; d.n = n; d.nt = nt;
+        d.panel_stride = (long)UPDATE_KD * n; d.state = state; d.state_stride = 4; d.prep = prep; d.prep_stride = 4L * n; d.acc_out = acc; d.acc_stride = nt; d.n = n; d.nt = nt;
         return d;
     }
     int local_update(int l) {
