@@ -22,6 +22,7 @@
 //                    substitutions with the pivot element broadcast by a lane
 //                    shuffle: no LDS, no barriers.
 #include "common.h"
+#include "wave.h"
 #include <cstdlib>
 
 namespace dq {
@@ -147,50 +148,85 @@ __global__ __launch_bounds__(256) void lu_solve_kernel(CMat LUm, const int* perm
     }
     const bool tri = mode == 2;
     const int kmax = tri ? min(c0 + CW - 1, n - 1) : n - 1;      // R1^-1 is upper triangular
+    // Both substitutions are serial chains of n steps; per step the pivot element is broadcast with
+    // v_readlane (k is wave-uniform; a ds_bpermute shuffle costs ~10x more) and the factor column of
+    // the NEXT step is already in flight (it does not depend on x), so no step waits on L2.
     // forward substitution, unit lower L
+    if (!tri) {
+        double lnext[NR];
 #pragma unroll
-    for (int q = 0; q < NR; ++q) {
-        if (tri) break;
-        for (int kk = 0; kk < 64; ++kk) {
-            const int k = 64 * q + kk;
-            if (k >= n) break;
-            double xk[CW];
+        for (int k2 = 0; k2 < NR; ++k2) { const int r = lane + 64 * k2; const double v = LU[prow[k2]]; lnext[k2] = (r > 0 && r < n) ? v : 0.0; }
 #pragma unroll
-            for (int cc = 0; cc < CW; ++cc) xk[cc] = __shfl(x[cc][q], kk, 64);
+        for (int q = 0; q < NR; ++q) {
+            for (int kk = 0; kk < 64; ++kk) {
+                const int k = 64 * q + kk;
+                if (k >= n) break;
+                double lcur[NR];
 #pragma unroll
-            for (int k2 = q; k2 < NR; ++k2) {
-                const int r = lane + 64 * k2;
-                if (r > k && r < n) {
-                    const double l = LU[prow[k2] + (long)n * k];
+                for (int k2 = 0; k2 < NR; ++k2) lcur[k2] = lnext[k2];
+                {   // unconditional loads (a branch around a load makes hipcc wait for it at the join), masked afterwards
+                    const long cb1 = (long)n * min(k + 1, n - 1);
 #pragma unroll
-                    for (int cc = 0; cc < CW; ++cc) x[cc][k2] -= l * xk[cc];
+                    for (int k2 = 0; k2 < NR; ++k2) { const int r = lane + 64 * k2; const double v = LU[prow[k2] + cb1]; lnext[k2] = (r > k + 1 && r < n) ? v : 0.0; }
+                }
+                double xk[CW];
+#pragma unroll
+                for (int cc = 0; cc < CW; ++cc) xk[cc] = readlane_f64(x[cc][q], kk);
+#pragma unroll
+                for (int k2 = q; k2 < NR; ++k2) {
+#pragma unroll
+                    for (int cc = 0; cc < CW; ++cc) x[cc][k2] -= lcur[k2] * xk[cc];       // lcur is 0 for rows <= k
                 }
             }
         }
     }
     // backward substitution, U
+    {
+        double unext[NR]; double dnext;
+        auto colbase = [&](int k, int pk) -> long { return tri ? (long)n * pk : (long)n * k; };
+        // prime the pipeline with column kmax
+        int pk_n;
+        {
+            int sel = 0;
 #pragma unroll
-    for (int q = NR - 1; q >= 0; --q) {
-        for (int kk = 63; kk >= 0; --kk) {
-            const int k = 64 * q + kk;
-            if (k > kmax) continue;
-            const int pk = __shfl(prow[q], kk, 64);                 // LU: pivot row of step k; tri: column of R holding R1[:, k]
-            const long colk = tri ? (long)n * pk : (long)n * k;
-            const double ukk = tri ? LU[k + colk] : LU[pk + colk];
-            double xk[CW];
+            for (int q2 = 0; q2 < NR; ++q2) if (q2 == (kmax >> 6)) sel = prow[q2];
+            pk_n = __builtin_amdgcn_readlane(sel, kmax & 63);
+            const long cb = colbase(kmax, pk_n);
+            dnext = tri ? LU[kmax + cb] : LU[pk_n + cb];
 #pragma unroll
-            for (int cc = 0; cc < CW; ++cc) {
-                const double v = __shfl(x[cc][q], kk, 64) / ukk;
-                xk[cc] = v;
-                if (lane == kk) x[cc][q] = v;
-            }
+            for (int k2 = 0; k2 < NR; ++k2) { const int r = lane + 64 * k2; const double v = LU[(tri ? min(r, n - 1) : prow[k2]) + cb]; unext[k2] = (r < kmax) ? v : 0.0; }
+        }
 #pragma unroll
-            for (int k2 = 0; k2 <= q; ++k2) {
-                const int r = lane + 64 * k2;
-                if (r < k) {
-                    const double u = tri ? LU[r + colk] : LU[prow[k2] + colk];
+        for (int q = NR - 1; q >= 0; --q) {
+            for (int kk = 63; kk >= 0; --kk) {
+                const int k = 64 * q + kk;
+                if (k > kmax) continue;
+                double ucur[NR]; const double ukk = dnext;
 #pragma unroll
-                    for (int cc = 0; cc < CW; ++cc) x[cc][k2] -= u * xk[cc];
+                for (int k2 = 0; k2 < NR; ++k2) ucur[k2] = unext[k2];
+                {                                              // prefetch column k-1 (clamped at 0: harmless reload)
+                    const int kn = k > 0 ? k - 1 : 0;
+                    int sel = 0;
+#pragma unroll
+                    for (int q2 = 0; q2 < NR; ++q2) if (q2 == (kn >> 6)) sel = prow[q2];
+                    const int pkn = __builtin_amdgcn_readlane(sel, kn & 63);
+                    const long cb = colbase(kn, pkn);
+                    dnext = tri ? LU[kn + cb] : LU[pkn + cb];
+#pragma unroll
+                    for (int k2 = 0; k2 < NR; ++k2) { const int r = lane + 64 * k2; const double v = LU[(tri ? min(r, n - 1) : prow[k2]) + cb]; unext[k2] = (r < kn) ? v : 0.0; }
+                }
+                const double rukk = 1.0 / ukk;
+                double xk[CW];
+#pragma unroll
+                for (int cc = 0; cc < CW; ++cc) {
+                    const double v = readlane_f64(x[cc][q], kk) * rukk;
+                    xk[cc] = v;
+                    if (lane == kk) x[cc][q] = v;
+                }
+#pragma unroll
+                for (int k2 = 0; k2 <= q; ++k2) {
+#pragma unroll
+                    for (int cc = 0; cc < CW; ++cc) x[cc][k2] -= ucur[k2] * xk[cc];        // ucur is 0 for rows >= k
                 }
             }
         }

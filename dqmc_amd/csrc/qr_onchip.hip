@@ -56,16 +56,30 @@ struct OcShared {
 };
 
 #define LCOL(kc, blk) sh.lcol[(((kc) - OC_KR) * 16 + (blk)) * OC_T + t]
+#ifdef DQ_QR_STAMPS
+#define QSTAMP(v) { unsigned long long _t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t) :: "memory"); v = _t; }
+#define QACC(slot, a, b) prof[slot] += (b) - (a);
+#else
+#define QSTAMP(v)
+#define QACC(slot, a, b)
+#endif
 
 // All steps i in row block JB (i = 16*JB .. min(16*JB+15, n-1)).
 template <int JB>
 __device__ __forceinline__ void qr_block(double (&a)[OC_KR][16], int& livem, const OcShared& sh, double* __restrict__ A,
-                                         double* tau, int* jpvt, int n, int t, int lane, int wave, int rg, int cl, int cbase) {
+                                         double* tau, int* jpvt, int n, int t, int lane, int wave, int rg, int cl, int cbase
+#ifdef DQ_QR_STAMPS
+                                         , unsigned long long (&prof)[8]
+#endif
+                                         ) {
     constexpr int NJ = 16 - JB;                                     // live row blocks JB .. 15
     const double tol3z = 1.0536712127723509e-08;                    // sqrt(2^-53)
     const int i_end = min(16 * JB + 16, n);
     for (int i = 16 * JB; i < i_end; ++i) {
         // ---- [A] pivot + publish its column ----
+#ifdef DQ_QR_STAMPS
+        unsigned long long q0, q1, q2, q3, q4, q5, q6; QSTAMP(q0)
+#endif
         unsigned long long best = sh.keys[0];
 #pragma unroll
         for (int k = 1; k < 8; ++k) { const unsigned long long o = sh.keys[k]; best = o > best ? o : best; }
@@ -103,7 +117,9 @@ __device__ __forceinline__ void qr_block(double (&a)[OC_KR][16], int& livem, con
                 sh.scal[0] = tau_l; sh.scal[1] = beta_l; sh.scal[2] = scale_l;
             }
         }
+        QSTAMP(q1)
         __syncthreads();
+        QSTAMP(q2)
         // ---- [B] Householder vector (dlarfg) ----
         const double tau_i = sh.scal[0], beta = sh.scal[1], scale = sh.scal[2];
         if (t < OC_N && t >= 16 * JB) {
@@ -116,6 +132,7 @@ __device__ __forceinline__ void qr_block(double (&a)[OC_KR][16], int& livem, con
         if (t == 0) { tau[i] = tau_i; jpvt[i] = p; sh.pposl[p] = i; }
         if ((p >> 3) == (cbase >> 3)) livem &= ~(1 << (p & 7));
         __syncthreads();
+        QSTAMP(q3)
         // ---- [C] apply H to my live columns: two passes over the live row blocks, two blocks per trip ----
         {
             const double* vb = sh.vbuf + 16 * JB + rg;
@@ -135,6 +152,7 @@ __device__ __forceinline__ void qr_block(double (&a)[OC_KR][16], int& livem, con
             }
 #pragma unroll
             for (int kc = 0; kc < OC_KC; ++kc) { s[kc] = row16_sum(s[kc]) * tau_i; if (!(livem & (1 << kc))) s[kc] = 0.0; }
+            QSTAMP(q4)
 #pragma unroll
             for (int j = 0; j < NJ; j += 2) {
                 const double v0 = vb[16 * j];
@@ -146,6 +164,7 @@ __device__ __forceinline__ void qr_block(double (&a)[OC_KR][16], int& livem, con
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        QSTAMP(q5)
         // ---- norm down-date (dlaqp2), new keys ----
         // The lanes that hold row i (rg == i & 15, register a[kc][JB]) drop their 8 row-i entries in LDS;
         // then lane q < 32 of every wave owns column 32*wave + q and runs ONE divide/sqrt chain
@@ -206,6 +225,8 @@ __device__ __forceinline__ void qr_block(double (&a)[OC_KR][16], int& livem, con
             key = wave_max_u64(key);
             if (lane == 0) sh.keys[wave] = key;
         }
+        QSTAMP(q6)
+        QACC(0, q0, q1) QACC(1, q1, q2) QACC(2, q2, q3) QACC(3, q3, q4) QACC(4, q4, q5) QACC(5, q5, q6)
         // ---- end of the row block: it is final -> store it as R0 ----
         if (i == i_end - 1) {
             const int r = 16 * JB + rg;
@@ -281,10 +302,22 @@ __global__ __launch_bounds__(OC_T) void qrcp_onchip_kernel(Mat Am, QrWork w, int
     }
     __syncthreads();
 
+#ifdef DQ_QR_STAMPS
+    unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long tk0; QSTAMP(tk0)
+#define DQ_QR_BLOCK(JB) if (16 * JB < n) qr_block<JB>(a, livem, sh, A, tau, jpvt, n, t, lane, wave, rg, cl, cbase, prof);
+#else
 #define DQ_QR_BLOCK(JB) if (16 * JB < n) qr_block<JB>(a, livem, sh, A, tau, jpvt, n, t, lane, wave, rg, cl, cbase);
+#endif
     DQ_QR_BLOCK(0) DQ_QR_BLOCK(1) DQ_QR_BLOCK(2) DQ_QR_BLOCK(3) DQ_QR_BLOCK(4) DQ_QR_BLOCK(5) DQ_QR_BLOCK(6) DQ_QR_BLOCK(7)
     DQ_QR_BLOCK(8) DQ_QR_BLOCK(9) DQ_QR_BLOCK(10) DQ_QR_BLOCK(11) DQ_QR_BLOCK(12) DQ_QR_BLOCK(13) DQ_QR_BLOCK(14) DQ_QR_BLOCK(15)
 #undef DQ_QR_BLOCK
+#ifdef DQ_QR_STAMPS
+    if ((t & 63) == 0 && (wave == 0 || wave == 7)) {
+        unsigned long long tk1; QSTAMP(tk1)
+        printf("qr wave %d n=%d total %llu | A(pivot+publish) %llu | barrier1 %llu | B %llu | C1(dots) %llu | C2(axpy) %llu | norms+keys %llu\n",
+               wave, n, tk1 - tk0, prof[0], prof[1], prof[2], prof[3], prof[4], prof[5]);
+    }
+#endif
 }
 #undef LCOL
 

@@ -12,3 +12,7 @@ rng = np.random.default_rng(0)
 for l in range(3):
     e.wrap_forward(l)
     print("accepted:", e.local_update_slice(l, *m.random_stream(rng, 1)), flush=True)
+
+import numpy as np
+M = np.random.default_rng(1).standard_normal((256, 256)) * np.exp(np.random.default_rng(2).uniform(-6, 6, 256))[None, :]
+print("to_ldr 256:"); lib.to_ldr(M); lib.to_ldr(M)
