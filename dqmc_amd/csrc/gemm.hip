@@ -18,6 +18,7 @@
 // Operands are read straight from L2: at the n <= 576 sizes of this code a
 // tile's panels are a few tens of KB and every matrix is L2/MALL resident.
 #include "common.h"
+#include <cstdlib>
 
 namespace dq {
 
@@ -81,8 +82,87 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDesc g, int tiles_per_dim
     }
 }
 
+// ---- latency-optimised variant for the n <= ~600 sizes of this code ----
+// One 256-thread block per 16x16 tile of C with K split over its 4 waves: 4 x more waves than the
+// one-wave-per-tile kernel (at n = 256: 1024 waves = one per SIMD of the chip), every wave issues
+// ALL of its operand loads (its quarter of K) before the first MFMA -- one L2 round trip instead of
+// one per 16-deep K block -- and the four partial tiles meet in LDS.  K quarters are rounded up to a
+// multiple of 16; out-of-range k contributes zeros.
+template <bool TRANSA, int KQ /* k per wave, multiple of 16 */>
+__global__ __launch_bounds__(256) void gemm_splitk_kernel(GemmDesc g, int tiles_per_dim) {
+    __shared__ double part[4][4][64];                 // [wave][reg][lane]
+    const int chain = blockIdx.y;
+    const int n = g.n;
+    const double* __restrict__ A = g.A.at(chain);
+    const double* __restrict__ B = g.B.at(chain);
+    double* __restrict__ C = g.C.at(chain);
+    const double* __restrict__ ks = g.ks.p ? g.ks.at(chain) : nullptr;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i0 = (blockIdx.x % tiles_per_dim) * 16, j0 = (blockIdx.x / tiles_per_dim) * 16;
+    const int r = lane & 15, kk = lane >> 4;
+    const int ia = min(i0 + r, n - 1), jb = min(j0 + r, n - 1);      // clamped: loads stay unconditional, results masked
+    const bool ia_ok = i0 + r < n, jb_ok = j0 + r < n;
+    const int kbeg = wave * KQ;
+    constexpr int NB = KQ / 16;
+    double av[NB][4], bv[NB][4];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int k = kbeg + 16 * b + 4 * kk + s;
+            const int kc = min(k, n - 1);
+            double a = TRANSA ? A[kc + (long)n * ia] : A[ia + (long)n * kc];
+            double bb = B[kc + (long)n * jb];
+            if (ks) a *= ks[kc];
+            const bool ok = k < n;
+            av[b][s] = (ok && ia_ok) ? a : 0.0;
+            bv[b][s] = (ok && jb_ok) ? bb : 0.0;
+        }
+    }
+    d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[b][s], av[b][s], acc, 0, 0, 0);
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) part[wave][reg][lane] = acc[reg];
+    __syncthreads();
+    // wave w finishes accumulator register w: lane holds C[i0 + r][j0 + kk + 4*w]
+    const double v4 = part[0][wave][lane] + part[1][wave][lane] + part[2][wave][lane] + part[3][wave][lane];
+    const int j = j0 + kk + 4 * wave;
+    if (ia_ok && j < n) {
+        double v = v4;
+        if (g.rs.p) v *= g.rs.at(chain)[i0 + r];
+        if (g.cs.p) v *= g.cs.at(chain)[j];
+        double* dst = C + (i0 + r) + (long)n * j;
+        if (g.accumulate) v += *dst;
+        *dst = v;
+    }
+}
+
+template <int KQ>
+static void launch_splitk(const GemmDesc& g, int n_chains, hipStream_t s) {
+    const int tiles = (g.n + 15) / 16;
+    dim3 grid(tiles * tiles, n_chains), block(256);
+    if (g.transA) hipLaunchKernelGGL((gemm_splitk_kernel<true, KQ>), grid, block, 0, s, g, tiles);
+    else hipLaunchKernelGGL((gemm_splitk_kernel<false, KQ>), grid, block, 0, s, g, tiles);
+}
+
 int launch_gemm(const GemmDesc& g, int n_chains, hipStream_t s) {
     const int n = g.n;
+    static const bool force_v1 = getenv("DQMC_GEMM_V1") != nullptr;      // A/B switch
+    if (!force_v1 && n <= 640) {
+        const int kq = ((n + 3) / 4 + 15) / 16 * 16;                     // k per wave
+        if (kq <= 16) launch_splitk<16>(g, n_chains, s);
+        else if (kq <= 32) launch_splitk<32>(g, n_chains, s);
+        else if (kq <= 48) launch_splitk<48>(g, n_chains, s);
+        else if (kq <= 64) launch_splitk<64>(g, n_chains, s);
+        else if (kq <= 96) launch_splitk<96>(g, n_chains, s);
+        else if (kq <= 128) launch_splitk<128>(g, n_chains, s);
+        else launch_splitk<160>(g, n_chains, s);
+        DQ_HIP(hipGetLastError());
+        return 0;
+    }
     const int tiles = (n + 31) / 32;
     dim3 grid(tiles * tiles, n_chains), block(256);
     const bool guard = (n % 32) != 0;
