@@ -66,6 +66,8 @@ def main():
     ap.add_argument("--config", default="cfg3")
     ap.add_argument("--chains-per-gpu", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--batched-chains", type=int, default=64,
+                    help="also time this many chains batched on one GPU (N=1 only; 0 disables); reported beside `value`, never as `value`")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     args = ap.parse_args()
 
@@ -130,13 +132,32 @@ def main():
                        "chains_per_gpu": C, "n_chains_total": world * C, "parallelism": f"independent chains, {world} gpu x {C} chain"},
             "acceptance": acc_rate, "max_wrap_err": s1.max_err, "mean_wrap_err": s1.mean_err,
             "roofline": {"kernel": "local-update slice kernels (scan_kernel + flush_kernel)", "bound": "hbm",
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         # HBM-side bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE,
+                         # 8 scan + 8 flush dispatches per slice; profiles/r01_pmc_fetch_write_cfg3_4slices.csv); cfg3 only
+                         "traffic": (8 * 1024.0 * (2 * 182.2 + 78.8 + 2 * 346.2 + 320.0) * C) if args.config == "cfg3" else None,
                          "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_launch_s * 1e3,
                          "launches": upd_launches, "accepted": upd_acc,
                          "time_share_of_sweep": (upd_ms * 1e-3) / dt},
             "gemm_chain": {"algorithmic_gemms_per_sweep": g_alg, "flop_per_sweep": g_alg * 2.0 * n ** 3,
                            "peak_tflops": FP64_MFMA_PEAK_TFLOPS},
         }
+        if world == 1 and args.batched_chains > 1 and C == 1:
+            # throughput mode: the same kernels advance B independent chains per launch (blockIdx.y = chain)
+            B = args.batched_chains
+            eb = model.engine(lib, device=local_rank, n_chains=B)
+            eb.set_fields(np.stack([model.random_fields(50000 + c) for c in range(B)])); eb.init()
+            rb = np.random.default_rng(4242)
+            def sweep_b():
+                eb.sweep_0_to_beta(*gen_streams(model, rb, B)); eb.sweep_beta_to_0(*gen_streams(model, rb, B))
+            sweep_b(); eb.sync()
+            tb = time.perf_counter(); nb = 2
+            for _ in range(nb):
+                sweep_b()
+            eb.sync(); tb = time.perf_counter() - tb
+            out["batched"] = {"chains_per_gpu": B, "value": B * nb / tb, "unit": "sweeps/s", "ms_per_step": 1e3 * tb / nb, "steps": nb,
+                              "note": "aggregate over independent chains sharing every kernel launch; not the headline config"}
+            eb.close()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model, 12345, args.cpu_budget)
         print(json.dumps(out), flush=True)
