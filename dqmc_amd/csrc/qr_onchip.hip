@@ -66,7 +66,7 @@ struct OcShared {
 
 // All steps i in row block JB (i = 16*JB .. min(16*JB+15, n-1)).
 template <int JB>
-__device__ __forceinline__ void qr_block(double (&a)[OC_KR][16], int& livem, const OcShared& sh, double* __restrict__ A,
+__device__ __forceinline__ void qr_block(double (&a)[OC_KR][16], int& livem, unsigned& wlive, const OcShared& sh, double* __restrict__ A,
                                          double* tau, int* jpvt, int n, int t, int lane, int wave, int rg, int cl, int cbase
 #ifdef DQ_QR_STAMPS
                                          , unsigned long long (&prof)[8]
@@ -85,28 +85,35 @@ __device__ __forceinline__ void qr_block(double (&a)[OC_KR][16], int& livem, con
         for (int k = 1; k < 8; ++k) { const unsigned long long o = sh.keys[k]; best = o > best ? o : best; }
         const int p = 255 - (int)(best & 0xFFULL);
         const int kcp = p & 7;
-        if (wave == (p >> 5)) {                // wave-uniform
+        if (wave == (p >> 5)) {                // wave-uniform: this wave holds the pivot column
             const bool mine = cl == ((p & 31) >> 3);
-            double ss = 0.0;
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const int r = 16 * (JB + j) + rg;
-                double x = 0.0;
-#pragma unroll
-                for (int kc = 0; kc < OC_KR; ++kc) if (kcp == kc) x = a[kc][JB + j];
-                if (kcp == 6) x = LCOL(6, JB + j);
-                if (kcp == 7) x = LCOL(7, JB + j);
-                if (mine) sh.xbuf[r] = x;
-                if (r > i) ss += x * x;
+            const int r_i = i & 15;            // lane of a DPP row that holds row i (slot JB)
+            double ss = 0.0, al_l = 0.0;
+            // one direct copy per column slot (a wave-uniform switch): a select chain over the six register
+            // columns costs ~12 v_cndmask per row block and sat on the critical path of every step
+#define DQ_PUBLISH(EXPR_J, EXPR_0)                                                        \
+            {                                                                             \
+                _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                          \
+                    const int r = 16 * (JB + j) + rg;                                     \
+                    const double x = EXPR_J;                                              \
+                    if (mine) sh.xbuf[r] = x;                                             \
+                    if (r > i) ss += x * x;                                               \
+                }                                                                         \
+                al_l = EXPR_0;                                                            \
             }
+            switch (kcp) {
+                case 0: DQ_PUBLISH(a[0][JB + j], a[0][JB]) break;
+                case 1: DQ_PUBLISH(a[1][JB + j], a[1][JB]) break;
+                case 2: DQ_PUBLISH(a[2][JB + j], a[2][JB]) break;
+                case 3: DQ_PUBLISH(a[3][JB + j], a[3][JB]) break;
+                case 4: DQ_PUBLISH(a[4][JB + j], a[4][JB]) break;
+                case 5: DQ_PUBLISH(a[5][JB + j], a[5][JB]) break;
+                case 6: DQ_PUBLISH(LCOL(6, JB + j), LCOL(6, JB)) break;
+                default: DQ_PUBLISH(LCOL(7, JB + j), LCOL(7, JB)) break;
+            }
+#undef DQ_PUBLISH
             ss = row16_sum(ss);                // every DPP row sums its own lanes; only the pivot's row is used
             // dlarfg scalars, computed once here (sqrt and two divisions cost ~0.4 us when all 8 waves repeat them)
-            const int r_i = i & 15;            // lane of the pivot row that holds row i (slot JB)
-            double al_l = 0.0;
-#pragma unroll
-            for (int kc = 0; kc < OC_KR; ++kc) if (kcp == kc) al_l = a[kc][JB];
-            if (kcp == 6) al_l = LCOL(6, JB);
-            if (kcp == 7) al_l = LCOL(7, JB);
             if (mine && rg == r_i) {
                 double tau_l = 0.0, beta_l = al_l, scale_l = 0.0;
                 if (ss != 0.0) {
@@ -131,6 +138,7 @@ __device__ __forceinline__ void qr_block(double (&a)[OC_KR][16], int& livem, con
         }
         if (t == 0) { tau[i] = tau_i; jpvt[i] = p; sh.pposl[p] = i; }
         if ((p >> 3) == (cbase >> 3)) livem &= ~(1 << (p & 7));
+        if ((p >> 5) == wave) wlive &= ~(1u << (p & 31));
         __syncthreads();
         QSTAMP(q3)
         // ---- [C] apply H to my live columns: two passes over the live row blocks, two blocks per trip ----
@@ -179,11 +187,7 @@ __device__ __forceinline__ void qr_block(double (&a)[OC_KR][16], int& livem, con
         int need = 0;                                          // bit kc (of MY columns) -> recompute
         double nn = 0.0; bool col_live = false; int need_col = 0;
         const int mycol = 32 * wave + (lane & 31);
-        {
-            // liveness of column mycol: its owner lanes are 16*(q >> 3) + any rg (q = lane & 31), bit q & 7 of their livem
-            const int lm = __shfl(livem, ((lane & 31) >> 3) << 4, 64);
-            col_live = lane < 32 && ((lm >> (lane & 7)) & 1);
-        }
+        col_live = lane < 32 && ((wlive >> (lane & 31)) & 1u);      // wlive: wave-uniform mask of this wave's live columns
         if (lane < 32 && col_live) {
             const double rv = sh.rowi[mycol];
             const double n1_ = sh.vn1[mycol];
@@ -272,6 +276,8 @@ __global__ __launch_bounds__(OC_T) void qrcp_onchip_kernel(Mat Am, QrWork w, int
 #pragma unroll
     for (int kc = 0; kc < OC_KC; ++kc) if (cbase + kc < n) livem |= 1 << kc;       // padding columns are never live
     if (t < OC_N) sh.pposl[t] = OC_N;
+    unsigned wlive = 0;                                             // bit q: column 32*wave + q is live (wave-uniform)
+    { const int c0w = 32 * wave; const int cnt = n - c0w; wlive = cnt >= 32 ? 0xFFFFFFFFu : (cnt > 0 ? ((1u << cnt) - 1u) : 0u); }
 
     // ---- load, initial norms, initial keys ----
     {
@@ -304,9 +310,9 @@ __global__ __launch_bounds__(OC_T) void qrcp_onchip_kernel(Mat Am, QrWork w, int
 
 #ifdef DQ_QR_STAMPS
     unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long tk0; QSTAMP(tk0)
-#define DQ_QR_BLOCK(JB) if (16 * JB < n) qr_block<JB>(a, livem, sh, A, tau, jpvt, n, t, lane, wave, rg, cl, cbase, prof);
+#define DQ_QR_BLOCK(JB) if (16 * JB < n) qr_block<JB>(a, livem, wlive, sh, A, tau, jpvt, n, t, lane, wave, rg, cl, cbase, prof);
 #else
-#define DQ_QR_BLOCK(JB) if (16 * JB < n) qr_block<JB>(a, livem, sh, A, tau, jpvt, n, t, lane, wave, rg, cl, cbase);
+#define DQ_QR_BLOCK(JB) if (16 * JB < n) qr_block<JB>(a, livem, wlive, sh, A, tau, jpvt, n, t, lane, wave, rg, cl, cbase);
 #endif
     DQ_QR_BLOCK(0) DQ_QR_BLOCK(1) DQ_QR_BLOCK(2) DQ_QR_BLOCK(3) DQ_QR_BLOCK(4) DQ_QR_BLOCK(5) DQ_QR_BLOCK(6) DQ_QR_BLOCK(7)
     DQ_QR_BLOCK(8) DQ_QR_BLOCK(9) DQ_QR_BLOCK(10) DQ_QR_BLOCK(11) DQ_QR_BLOCK(12) DQ_QR_BLOCK(13) DQ_QR_BLOCK(14) DQ_QR_BLOCK(15)
