@@ -78,3 +78,27 @@ def test_two_rank_replica_exchange_over_gloo(tmp_path):
         m = HubbardModel(L1=4, L2=4, U=4.0, beta=beta, nt=20, n_stab=10)
         e = m.engine(oracle()); e.set_fields(logs[r][2]["after"]); e.init()
         assert np.abs(e.get_G() - logs[r][2]["G"]).max() < 1e-12
+
+
+def _pt_worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from dqmc_amd.launch import dist_init, finalize
+    from dqmc_amd.pt_run import run_pt
+    from oracle import oracle
+    d = dist_init("gloo")
+    lines = []
+    rate, attempt, accepted = run_pt(d, lambda m: m.engine(oracle()), [2.0, 1.8], L=4, U=4.0, nt=20, n_stab=10, therm=1, sweeps=6,
+                                     sweep_steps=2, log=lines.append)
+    with open(os.path.join(out_dir, f"pt{rank}.txt"), "w") as fh:
+        fh.write(f"{attempt} {accepted} {rate}\n" + "\n".join(lines))
+    finalize(d)
+
+
+def test_parallel_tempering_driver_two_ranks(tmp_path):
+    """The cfg-4 driver loop (barrier + replica_exchange every sweep_steps sweeps) end to end on gloo."""
+    mp.spawn(_pt_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    a0 = open(tmp_path / "pt0.txt").read().split("\n"); a1 = open(tmp_path / "pt1.txt").read().split("\n")
+    assert a0[0].split()[0] == "3" and a1[0].split()[0] == "3"          # 6 sweeps, exchange every 2nd
+    assert "exchange rate" in a0[1] and a1[1:] == [""]                     # only rank 0 reports (source/main.cpp:204)

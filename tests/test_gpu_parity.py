@@ -245,6 +245,38 @@ def test_cfg3_one_block_then_properties(hip, orc):
     assert np.abs(G3 - e4.get_G()).max() <= 1e-8 * max(1.0, np.abs(G3).max())
 
 
+def test_cfg5_size_streaming_kernels(hip, orc):
+    """cfg 5 (24x24, beta=10, Ltau=400, n_stab=10): N = 576 takes the streaming QRCP (9 rows per lane),
+    the guarded GEMM tiles and the 576-thread update kernel.  The oracle (LAPACK back end when present,
+    for speed) checks G(0,0) / log det from scratch and one stabilisation block of the forward sweep."""
+    m = HubbardModel(**CONFIGS["cfg5"]); f = m.random_fields(55)
+    e = m.engine(hip); e.set_fields(f); e.init()
+    fast = orc.set_backend("lapack")
+    try:
+        o = m.engine(orc); o.set_fields(f); o.init()
+        Go = o.get_G(); scale = max(1.0, np.abs(Go).max())
+        err = np.abs(e.get_G() - Go).max()
+        print(f"cfg5 init: max|dG| = {err:.3e}, max|G| = {scale:.3e}, lapack oracle = {fast}")
+        assert err <= 1e-9 * scale
+        assert abs(e.get_logdet() - o.get_logdet()) < 1e-9 * abs(o.get_logdet())
+        rng = np.random.default_rng(6)
+        for l in range(3):
+            s = m.random_stream(rng, 1)
+            e.wrap_forward(l); o.wrap_forward(l)
+            assert e.local_update_slice(l, *s) == o.local_update_slice(l, *s)
+        assert (e.get_fields() == o.get_fields()).all()
+        assert np.abs(e.get_G() - o.get_G()).max() <= 1e-7 * max(1.0, np.abs(o.get_G()).max())
+    finally:
+        orc.set_backend("builtin")
+    # one full sweep: exercises every stabilisation path at this size; consistency with a from-scratch evaluation
+    s1, s2 = m.random_stream(rng), m.random_stream(rng)
+    e.sweep_0_to_beta(*s1); e.sweep_beta_to_0(*s2)
+    st = e.stats(); G1 = e.get_G()
+    assert st.n_err == 2 * m.n_stack and 0.2 < st.n_accepted / st.n_proposed < 0.8
+    e2 = m.engine(hip); e2.set_fields(e.get_fields()); e2.init()
+    assert np.abs(G1 - e2.get_G()).max() <= 1e-8 * max(1.0, np.abs(G1).max())
+
+
 def test_batched_engine(hip, orc):
     m = HubbardModel(**CONFIGS["cfg2"]); C = 3
     f = np.stack([m.random_fields(20 + c) for c in range(C)])
