@@ -89,7 +89,11 @@ int launch_fold_stats(DevStats* st, const int* acc, long acc_stride, int n_slice
 struct QrWork {
     double* tau; long tau_stride;      // n per chain
     int* jpvt; long jpvt_stride;       // n per chain
+    unsigned long long* sync = nullptr; long sync_stride = 0;   // cooperative QRCP: granule records, >= qrcp_coop_sync_granules() per chain
+    int* abort_words = nullptr;                                 // cooperative QRCP: one word per chain
+    int* info = nullptr;                                        // |= 2 when a cooperative factorisation gave up waiting
 };
+long qrcp_coop_sync_granules();
 int launch_to_ldr(Mat A, Mat L, Vec d, Mat R, QrWork w, int n, int n_chains, hipStream_t s);
 
 // ---- lu.hip -----------------------------------------------------------------

@@ -48,6 +48,8 @@ struct Ctx {
     double* vpool = nullptr;                   // vectors: 8 * C * n
     int* ipool = nullptr;                      // 3 * C * n ints + info
     double* spool = nullptr;                   // scalars: 4 * C
+    unsigned long long* qsync = nullptr;       // cooperative QRCP records
+    int* qabort = nullptr;                     // cooperative QRCP abort words: C
 
     Mat T(int k) const { return Mat{pool + (long)k * C * nn, nn}; }
     Vec V(int k) const { return Vec{vpool + (long)k * C * n, (long)n}; }
@@ -66,6 +68,8 @@ struct Ctx {
         DQ_HIP(hipMalloc(&vpool, sizeof(double) * 8 * C * n));
         DQ_HIP(hipMalloc(&ipool, sizeof(int) * (3L * C * n + 4)));
         DQ_HIP(hipMalloc(&spool, sizeof(double) * 4 * C));
+        DQ_HIP(hipMalloc(&qsync, sizeof(unsigned long long) * qrcp_coop_sync_granules() * C));
+        DQ_HIP(hipMalloc(&qabort, sizeof(int) * C));
         DQ_HIP(hipMemsetAsync(ipool, 0, sizeof(int) * (3L * C * n + 4), stream));
         return 0;
     }
@@ -74,6 +78,8 @@ struct Ctx {
         if (vpool) (void)hipFree(vpool);
         if (ipool) (void)hipFree(ipool);
         if (spool) (void)hipFree(spool);
+        if (qsync) (void)hipFree(qsync);
+        if (qabort) (void)hipFree(qabort);
         if (stream) (void)hipStreamDestroy(stream);
     }
 
@@ -87,6 +93,7 @@ struct Ctx {
     int to_ldr(Mat A, LdrRef out, bool direct = true) {
         const bool keep = direct && out.jpvt != nullptr;
         QrWork w{V(7).p, (long)n, keep ? out.jpvt : jpvt(), (long)n};
+        w.sync = qsync; w.sync_stride = qrcp_coop_sync_granules(); w.abort_words = qabort; w.info = info();
         if (out.tri) *out.tri = keep;
         return launch_to_ldr(A, out.L, out.d, out.R, w, n, C, stream);
     }
@@ -374,6 +381,7 @@ struct Engine {
         }
         int h_info = 0;
         DQ_HIP(hipMemcpy(&h_info, ctx.info(), sizeof(int), hipMemcpyDeviceToHost));
+        if (h_info & 2) { set_error("cooperative QRCP gave up waiting for a partner workgroup (not co-resident?)"); (void)hipMemset(ctx.info(), 0, sizeof(int)); return DQMC_ENUMERIC; }
         if (h_info) { set_error("LU factorisation hit a zero or NaN pivot"); (void)hipMemset(ctx.info(), 0, sizeof(int)); return DQMC_ENUMERIC; }
         return 0;
     }
