@@ -56,6 +56,13 @@ struct OcShared {
 };
 
 #define LCOL(kc, blk) sh.lcol[(((kc) - OC_KR) * 16 + (blk)) * OC_T + t]
+// Column map.  Thread pair index u = 4*wave + cl (0..31).  The two LDS-resident columns of a thread are the LOW
+// column indices, c = 2u + (kc-6) in 0..63; the six register columns are c = 64 + 6u + kc.  In the matrices this
+// code factors, (Bbar L) diag(d), column norms fall with the column index (d is sorted by the previous QRCP), so
+// low columns are pivoted -- and go dead -- within the first ~64 steps: the LDS traffic (whose write bandwidth
+// paced the update phase) disappears for the remaining three quarters of the factorisation.  Any matrix is still
+// factored correctly; the map only decides which columns pay LDS latency.
+#define COLOF(kc) ((kc) < OC_KR ? 64 + 6 * cbase + (kc) : 2 * cbase + ((kc) - OC_KR))      /* cbase = pair index u here */
 #ifdef DQ_QR_STAMPS
 #define QSTAMP(v) { unsigned long long _t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t) :: "memory"); v = _t; }
 #define QACC(slot, a, b) prof[slot] += (b) - (a);
@@ -84,9 +91,12 @@ __device__ __forceinline__ void qr_block(double (&a)[OC_KR][16], int& livem, uns
 #pragma unroll
         for (int k = 1; k < 8; ++k) { const unsigned long long o = sh.keys[k]; best = o > best ? o : best; }
         const int p = 255 - (int)(best & 0xFFULL);
-        const int kcp = p & 7;
-        if (wave == (p >> 5)) {                // wave-uniform: this wave holds the pivot column
-            const bool mine = cl == ((p & 31) >> 3);
+        // owner of column p: pair index up, slot kcp; position qp of p among its wave's 32 columns
+        const int up = p < 64 ? (p >> 1) : (p - 64) / 6;
+        const int kcp = p < 64 ? OC_KR + (p & 1) : (p - 64) % 6;
+        const int qp = p < 64 ? (p & 7) : 8 + (p - 64) % 24;
+        if (wave == (up >> 2)) {               // wave-uniform: this wave holds the pivot column
+            const bool mine = cl == (up & 3);
             const int r_i = i & 15;            // lane of a DPP row that holds row i (slot JB)
             double ss = 0.0, al_l = 0.0;
             // one direct copy per column slot (a wave-uniform switch): a select chain over the six register
@@ -137,8 +147,8 @@ __device__ __forceinline__ void qr_block(double (&a)[OC_KR][16], int& livem, uns
             sh.vbuf[r] = vr;
         }
         if (t == 0) { tau[i] = tau_i; jpvt[i] = p; sh.pposl[p] = i; }
-        if ((p >> 3) == (cbase >> 3)) livem &= ~(1 << (p & 7));
-        if ((p >> 5) == wave) wlive &= ~(1u << (p & 31));
+        if (up == cbase) livem &= ~(1 << kcp);
+        if ((up >> 2) == wave) wlive &= ~(1u << qp);
         __syncthreads();
         QSTAMP(q3)
         // ---- [C] apply H to my live columns: two passes over the live row blocks, two blocks per trip ----
@@ -175,18 +185,19 @@ __device__ __forceinline__ void qr_block(double (&a)[OC_KR][16], int& livem, uns
         QSTAMP(q5)
         // ---- norm down-date (dlaqp2), new keys ----
         // The lanes that hold row i (rg == i & 15, register a[kc][JB]) drop their 8 row-i entries in LDS;
-        // then lane q < 32 of every wave owns column 32*wave + q and runs ONE divide/sqrt chain
+        // then lane q < 32 of every wave owns the wave's q-th column (q < 8: LDS columns 8w+q, else 64+24w+q-8) and runs ONE divide/sqrt chain
         // (eight sequential chains in four lanes cost > 1 us per step).  A column whose norm must be
         // recomputed (cancellation) is flagged and handled cooperatively by its 16 row-group lanes (rare).
         if (rg == (i & 15)) {
 #pragma unroll
-            for (int kc = 0; kc < OC_KC; ++kc) sh.rowi[cbase + kc] = kc < OC_KR ? a[kc < OC_KR ? kc : 0][JB] : LCOL(kc, JB);
+            for (int kc = 0; kc < OC_KC; ++kc) sh.rowi[COLOF(kc)] = kc < OC_KR ? a[kc < OC_KR ? kc : 0][JB] : LCOL(kc, JB);
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);                    // lgkmcnt(0): my wave's LDS writes are done (wave-local hand-off)
         __builtin_amdgcn_wave_barrier();
         int need = 0;                                          // bit kc (of MY columns) -> recompute
         double nn = 0.0; bool col_live = false; int need_col = 0;
-        const int mycol = 32 * wave + (lane & 31);
+        const int ql = lane & 31;                              // lane q < 32 owns the q-th column of this wave
+        const int mycol = ql < 8 ? 8 * wave + ql : 64 + 24 * wave + (ql - 8);
         col_live = lane < 32 && ((wlive >> (lane & 31)) & 1u);      // wlive: wave-uniform mask of this wave's live columns
         if (lane < 32 && col_live) {
             const double rv = sh.rowi[mycol];
@@ -201,10 +212,13 @@ __device__ __forceinline__ void qr_block(double (&a)[OC_KR][16], int& livem, uns
         }
         const unsigned long long needmask = __ballot(need_col);   // bit q: column 32*wave + q needs a recompute
         if (needmask != 0ULL) {
-            need = (int)((needmask >> (8 * cl)) & 0xFFULL);        // my thread's 8 columns are q = 8*cl .. 8*cl+7
+            // my thread's columns sit at wave positions q = 8 + 6*cl + kc (register slots) and q = 2*cl + kc - 6 (LDS slots)
+            need = (int)((needmask >> (8 + 6 * cl)) & 0x3FULL) | (int)(((needmask >> (2 * cl)) & 0x3ULL) << 6);
 #pragma unroll
             for (int kc = 0; kc < OC_KC; ++kc) {
-                if ((needmask >> kc) & 0x01010101ULL) {            // some DPP row of this wave needs column slot kc
+                const unsigned long long rows_kc = kc < OC_KR ? (0x04104100ULL << kc)                     /* q = 8+kc, 14+kc, 20+kc, 26+kc */
+                                                             : (0x55ULL << (kc - OC_KR));                  /* q = kc-6, +2, +4, +6 */
+                if (needmask & rows_kc) {                          // some DPP row of this wave needs column slot kc
                     double tl = 0.0;
 #pragma unroll
                     for (int j = 0; j < NJ; ++j) {
@@ -216,7 +230,7 @@ __device__ __forceinline__ void qr_block(double (&a)[OC_KR][16], int& livem, uns
                     tl = row16_sum(tl);
                     if (rg == 0 && ((need >> kc) & 1)) {
                         const double v2 = (i + 1 < n) ? sqrt(tl) : 0.0;
-                        sh.vn1[cbase + kc] = v2; sh.vn2[cbase + kc] = v2;
+                        sh.vn1[COLOF(kc)] = v2; sh.vn2[COLOF(kc)] = v2;
                     }
                 }
             }
@@ -239,8 +253,8 @@ __device__ __forceinline__ void qr_block(double (&a)[OC_KR][16], int& livem, uns
                 // position are R0 entries; the diagonal (beta) and the reflector below it are already in A.
 #pragma unroll
                 for (int kc = 0; kc < OC_KC; ++kc) {
-                    if (cbase + kc < n && ((livem & (1 << kc)) ? r <= i : r < sh.pposl[cbase + kc]))
-                        A[r + (long)n * (cbase + kc)] = kc < OC_KR ? a[kc < OC_KR ? kc : 0][JB] : LCOL(kc, JB);
+                    if (COLOF(kc) < n && ((livem & (1 << kc)) ? r <= i : r < sh.pposl[COLOF(kc)]))
+                        A[r + (long)n * COLOF(kc)] = kc < OC_KR ? a[kc < OC_KR ? kc : 0][JB] : LCOL(kc, JB);
                 }
             }
         }
@@ -269,15 +283,15 @@ __global__ __launch_bounds__(OC_T) void qrcp_onchip_kernel(Mat Am, QrWork w, int
     int* jpvt = w.jpvt + (long)chain * w.jpvt_stride;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int rg = lane & 15, cl = lane >> 4;
-    const int cbase = 32 * wave + 8 * cl;
+    const int cbase = 4 * wave + cl;                                // pair index u of the column map (COLOF)
 
     double a[OC_KR][16];
     int livem = 0;                                                  // bit kc: my column kc has not been pivoted yet
 #pragma unroll
-    for (int kc = 0; kc < OC_KC; ++kc) if (cbase + kc < n) livem |= 1 << kc;       // padding columns are never live
+    for (int kc = 0; kc < OC_KC; ++kc) if (COLOF(kc) < n) livem |= 1 << kc;        // padding columns are never live
     if (t < OC_N) sh.pposl[t] = OC_N;
     unsigned wlive = 0;                                             // bit q: column 32*wave + q is live (wave-uniform)
-    { const int c0w = 32 * wave; const int cnt = n - c0w; wlive = cnt >= 32 ? 0xFFFFFFFFu : (cnt > 0 ? ((1u << cnt) - 1u) : 0u); }
+    for (int q = 0; q < 32; ++q) { const int c = q < 8 ? 8 * wave + q : 64 + 24 * wave + (q - 8); if (c < n) wlive |= 1u << q; }
 
     // ---- load, initial norms, initial keys ----
     {
@@ -289,7 +303,7 @@ __global__ __launch_bounds__(OC_T) void qrcp_onchip_kernel(Mat Am, QrWork w, int
             const int r = 16 * j + rg;
 #pragma unroll
             for (int kc = 0; kc < OC_KC; ++kc) {
-                const double x = (r < n && cbase + kc < n) ? A[r + (long)n * (cbase + kc)] : 0.0;
+                const double x = (r < n && COLOF(kc) < n) ? A[r + (long)n * COLOF(kc)] : 0.0;
                 if (kc < OC_KR) a[kc < OC_KR ? kc : 0][j] = x; else LCOL(kc, j) = x;
                 nrm[kc] += x * x;
             }
@@ -299,8 +313,8 @@ __global__ __launch_bounds__(OC_T) void qrcp_onchip_kernel(Mat Am, QrWork w, int
         for (int kc = 0; kc < OC_KC; ++kc) {
             const double nn = sqrt(row16_sum(nrm[kc]));
             if (rg == 0) {
-                sh.vn1[cbase + kc] = nn; sh.vn2[cbase + kc] = nn;
-                if (livem & (1 << kc)) { const unsigned long long k = norm_key(nn, cbase + kc); key = k > key ? k : key; }
+                sh.vn1[COLOF(kc)] = nn; sh.vn2[COLOF(kc)] = nn;
+                if (livem & (1 << kc)) { const unsigned long long k = norm_key(nn, COLOF(kc)); key = k > key ? k : key; }
             }
         }
         key = wave_max_u64(key);
@@ -326,6 +340,7 @@ __global__ __launch_bounds__(OC_T) void qrcp_onchip_kernel(Mat Am, QrWork w, int
 #endif
 }
 #undef LCOL
+#undef COLOF
 
 int launch_qrcp_onchip(Mat A, QrWork w, int n, int n_chains, hipStream_t s) {
     if (n > OC_N) { set_error("on-chip QRCP supports n <= 256"); return -1; }
