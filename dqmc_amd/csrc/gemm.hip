@@ -140,6 +140,92 @@ __global__ __launch_bounds__(256) void gemm_splitk_kernel(GemmDesc g, int tiles_
     }
 }
 
+// ---- throughput variant for batched engines (many chains per launch) ----
+// 64x64 tile of C per 256-thread block, 32x32 per wave (2x2 MFMA tiles), K walked in 16-deep stages
+// through LDS (A stage [16][64] + B stage [16][64], rows padded to 80 doubles so the four k-groups
+// of a wave read disjoint banks), next stage's global loads in flight during the MFMAs.
+// Operand traffic per tile is 4x lower than one-wave-per-tile kernels: at 64 chains the split-K
+// kernel is L2-bandwidth bound (13 TFLOP/s), this one is bound by the fp64 MFMA rate.
+// Requires n % 64 == 0 (N = 64, 256, 576 of the reference configurations).
+template <bool TRANSA>
+__global__ __launch_bounds__(256) void gemm_tile64_kernel(GemmDesc g, int tiles_per_dim) {
+    constexpr int LDT = 80;
+    __shared__ double As[2][16][LDT];
+    __shared__ double Bs[2][16][LDT];
+    const int chain = blockIdx.y;
+    const int n = g.n;
+    const double* __restrict__ A = g.A.at(chain);
+    const double* __restrict__ B = g.B.at(chain);
+    double* __restrict__ C = g.C.at(chain);
+    const double* __restrict__ ks = g.ks.p ? g.ks.at(chain) : nullptr;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int i0 = (blockIdx.x % tiles_per_dim) * 64, j0 = (blockIdx.x / tiles_per_dim) * 64;
+    const int r = lane & 15, kk = lane >> 4;
+    const int wi = (wave & 1) * 32, wj = (wave >> 1) * 32;
+    // staging roles
+    const int ai = t & 63, akq = t >> 6;            // A: row ai, k = 4*akq + s
+    const int bkp = t & 7, bj = t >> 3;             // B: k pair 2*bkp, columns bj and bj + 32
+    double ra[4]; double2 rb0, rb1;
+    auto load_stage = [&](int kb) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int k = kb + 4 * akq + s;
+            double v = TRANSA ? A[k + (long)n * (i0 + ai)] : A[(i0 + ai) + (long)n * k];
+            if (ks) v *= ks[k];
+            ra[s] = v;
+        }
+        rb0 = *reinterpret_cast<const double2*>(B + (kb + 2 * bkp) + (long)n * (j0 + bj));
+        rb1 = *reinterpret_cast<const double2*>(B + (kb + 2 * bkp) + (long)n * (j0 + bj + 32));
+    };
+    auto store_stage = [&](int buf) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) As[buf][4 * akq + s][ai] = ra[s];
+        Bs[buf][2 * bkp][bj] = rb0.x; Bs[buf][2 * bkp + 1][bj] = rb0.y;
+        Bs[buf][2 * bkp][bj + 32] = rb1.x; Bs[buf][2 * bkp + 1][bj + 32] = rb1.y;
+    };
+    d4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = d4{0.0, 0.0, 0.0, 0.0};
+    load_stage(0); store_stage(0);
+    __syncthreads();
+    const int nstage = n / 16;
+    for (int st = 0; st < nstage; ++st) {
+        const int buf = st & 1;
+        if (st + 1 < nstage) load_stage(16 * (st + 1));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k = 4 * q + kk;
+            const double a0 = As[buf][k][wi + r], a1 = As[buf][k][wi + 16 + r];
+            const double b0 = Bs[buf][k][wj + r], b1 = Bs[buf][k][wj + 16 + r];
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(b0, a0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, a0, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(b0, a1, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, a1, acc[1][1], 0, 0, 0);
+        }
+        if (st + 1 < nstage) store_stage(buf ^ 1);
+        __syncthreads();
+    }
+    // lane holds C[i0 + wi + 16*ti + r][j0 + wj + 16*tj + kk + 4*reg]
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti) {
+        const int i = i0 + wi + 16 * ti + r;
+        const double rsv = g.rs.p ? g.rs.at(chain)[i] : 1.0;
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int j = j0 + wj + 16 * tj + kk + 4 * reg;
+                double v = acc[ti][tj][reg] * rsv;
+                if (g.cs.p) v *= g.cs.at(chain)[j];
+                double* dst = C + i + (long)n * j;
+                if (g.accumulate) v += *dst;
+                *dst = v;
+            }
+    }
+}
+
 template <int KQ>
 static void launch_splitk(const GemmDesc& g, int n_chains, hipStream_t s) {
     const int tiles = (g.n + 15) / 16;
@@ -151,6 +237,15 @@ static void launch_splitk(const GemmDesc& g, int n_chains, hipStream_t s) {
 int launch_gemm(const GemmDesc& g, int n_chains, hipStream_t s) {
     const int n = g.n;
     static const bool force_v1 = getenv("DQMC_GEMM_V1") != nullptr;      // A/B switch
+    static const bool no_tile64 = getenv("DQMC_GEMM_NO_TILE64") != nullptr;
+    if (!force_v1 && !no_tile64 && n % 64 == 0 && (long)n_chains * (n / 64) * (n / 64) >= 256) {     // enough 64x64 tiles to fill 256 CUs
+        const int tiles = n / 64;
+        dim3 grid(tiles * tiles, n_chains), block(256);
+        if (g.transA) hipLaunchKernelGGL((gemm_tile64_kernel<true>), grid, block, 0, s, g, tiles);
+        else hipLaunchKernelGGL((gemm_tile64_kernel<false>), grid, block, 0, s, g, tiles);
+        DQ_HIP(hipGetLastError());
+        return 0;
+    }
     if (!force_v1 && n <= 640) {
         const int kq = ((n + 3) / 4 + 15) / 16 * 16;                     // k per wave
         if (kq <= 16) launch_splitk<16>(g, n_chains, s);

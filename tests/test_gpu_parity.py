@@ -298,6 +298,26 @@ def test_batched_engine(hip, orc):
         assert st[c].n_accepted == os_[c].stats().n_accepted
 
 
+def test_large_batch_uses_throughput_gemm(hip, orc):
+    """256 chains of cfg 2 in one engine: enough 64x64 tiles for the LDS-tiled throughput GEMM
+    (gemm_tile64_kernel) to be selected; a sample of chains is checked against the oracle."""
+    m = HubbardModel(**CONFIGS["cfg2"]); C = 256
+    f = np.stack([m.random_fields(1000 + c) for c in range(C)])
+    e = m.engine(hip, n_chains=C); e.set_fields(f); e.init()
+    rng = np.random.default_rng(9)
+    streams = [m.random_stream(rng) for _ in range(C)]
+    s = tuple(np.stack([st[k] for st in streams]) for k in range(3))
+    G0 = e.get_G()
+    e.sweep_0_to_beta(*s)
+    G1 = e.get_G(); f1 = e.get_fields(); st = e.stats()
+    for c in (0, 1, 17, 100, 254, 255):
+        o = m.engine(orc); o.set_fields(f[c]); o.init()
+        assert close(G0[c], o.get_G())
+        o.sweep_0_to_beta(*streams[c])
+        assert (f1[c] == o.get_fields()).all() and close(G1[c], o.get_G())
+        assert st[c].n_accepted == o.stats().n_accepted
+
+
 def test_error_codes(hip):
     from dqmc_amd import DqmcError
     m = HubbardModel(**CONFIGS["cfg1"]); e = m.engine(hip); e.set_fields(m.random_fields(1))
