@@ -149,84 +149,78 @@ __global__ __launch_bounds__(256) void lu_solve_kernel(CMat LUm, const int* perm
     const bool tri = mode == 2;
     const int kmax = tri ? min(c0 + CW - 1, n - 1) : n - 1;      // R1^-1 is upper triangular
     // Both substitutions are serial chains of n steps; per step the pivot element is broadcast with
-    // v_readlane (k is wave-uniform; a ds_bpermute shuffle costs ~10x more) and the factor column of
-    // the NEXT step is already in flight (it does not depend on x), so no step waits on L2.
+    // v_readlane (k is wave-uniform; a ds_bpermute shuffle costs ~10x more) and the factor columns of
+    // the next FOUR steps are already in flight (they do not depend on x): a one-deep prefetch left
+    // every step waiting on L2.  The ring of four is unrolled by hand so its slots are static registers.
+    constexpr int PD = 4;
     // forward substitution, unit lower L
     if (!tri) {
-        double lnext[NR];
+        double lq[PD][NR];
+        auto fetchL = [&](int slot, int k) {
+            const long cb = (long)n * min(k, n - 1);
 #pragma unroll
-        for (int k2 = 0; k2 < NR; ++k2) { const int r = lane + 64 * k2; const double v = LU[prow[k2]]; lnext[k2] = (r > 0 && r < n) ? v : 0.0; }
+            for (int k2 = 0; k2 < NR; ++k2) { const int r = lane + 64 * k2; const double v = LU[prow[k2] + cb]; lq[slot][k2] = (r > k && r < n) ? v : 0.0; }
+        };
+        fetchL(0, 0); fetchL(1, 1); fetchL(2, 2); fetchL(3, 3);
 #pragma unroll
         for (int q = 0; q < NR; ++q) {
-            for (int kk = 0; kk < 64; ++kk) {
-                const int k = 64 * q + kk;
-                if (k >= n) break;
-                double lcur[NR];
+            for (int kb = 0; kb < 64; kb += PD) {
+                if (64 * q + kb >= n) break;
 #pragma unroll
-                for (int k2 = 0; k2 < NR; ++k2) lcur[k2] = lnext[k2];
-                {   // unconditional loads (a branch around a load makes hipcc wait for it at the join), masked afterwards
-                    const long cb1 = (long)n * min(k + 1, n - 1);
+                for (int e = 0; e < PD; ++e) {
+                    const int k = 64 * q + kb + e;
+                    double xk[CW];
 #pragma unroll
-                    for (int k2 = 0; k2 < NR; ++k2) { const int r = lane + 64 * k2; const double v = LU[prow[k2] + cb1]; lnext[k2] = (r > k + 1 && r < n) ? v : 0.0; }
-                }
-                double xk[CW];
+                    for (int cc = 0; cc < CW; ++cc) xk[cc] = readlane_f64(x[cc][q], kb + e);
 #pragma unroll
-                for (int cc = 0; cc < CW; ++cc) xk[cc] = readlane_f64(x[cc][q], kk);
+                    for (int k2 = q; k2 < NR; ++k2) {
 #pragma unroll
-                for (int k2 = q; k2 < NR; ++k2) {
-#pragma unroll
-                    for (int cc = 0; cc < CW; ++cc) x[cc][k2] -= lcur[k2] * xk[cc];       // lcur is 0 for rows <= k
+                        for (int cc = 0; cc < CW; ++cc) x[cc][k2] -= lq[e][k2] * xk[cc];      // lq is 0 for rows <= k and for k >= n
+                    }
+                    fetchL(e, k + PD);
                 }
             }
         }
     }
     // backward substitution, U
     {
-        double unext[NR]; double dnext;
-        auto colbase = [&](int k, int pk) -> long { return tri ? (long)n * pk : (long)n * k; };
-        // prime the pipeline with column kmax
-        int pk_n;
-        {
+        double uq[PD][NR]; double dq_[PD];
+        auto fetchU = [&](int slot, int k) {
+            const int kc = min(max(k, 0), n - 1);                           // clamped: out-of-range steps load a harmless valid column
             int sel = 0;
 #pragma unroll
-            for (int q2 = 0; q2 < NR; ++q2) if (q2 == (kmax >> 6)) sel = prow[q2];
-            pk_n = __builtin_amdgcn_readlane(sel, kmax & 63);
-            const long cb = colbase(kmax, pk_n);
-            dnext = tri ? LU[kmax + cb] : LU[pk_n + cb];
+            for (int q2 = 0; q2 < NR; ++q2) if (q2 == (kc >> 6)) sel = prow[q2];
+            const int pk = __builtin_amdgcn_readlane(sel, kc & 63);         // LU: pivot row of step k; tri: column of R holding R1[:, k]
+            const long cb = tri ? (long)n * pk : (long)n * kc;
+            dq_[slot] = tri ? LU[kc + cb] : LU[pk + cb];
 #pragma unroll
-            for (int k2 = 0; k2 < NR; ++k2) { const int r = lane + 64 * k2; const double v = LU[(tri ? min(r, n - 1) : prow[k2]) + cb]; unext[k2] = (r < kmax) ? v : 0.0; }
-        }
+            for (int k2 = 0; k2 < NR; ++k2) { const int r = lane + 64 * k2; const double v = LU[(tri ? min(r, n - 1) : prow[k2]) + cb]; uq[slot][k2] = (r < kc) ? v : 0.0; }
+        };
+        // steps run k = ktop .. 0 with ktop = 64*NR - 1 rounded so that slot e serves k == e' (mod 4) statically
+        const int ktop = 64 * NR - 1;
+        fetchU(3, ktop); fetchU(2, ktop - 1); fetchU(1, ktop - 2); fetchU(0, ktop - 3);
 #pragma unroll
         for (int q = NR - 1; q >= 0; --q) {
-            for (int kk = 63; kk >= 0; --kk) {
-                const int k = 64 * q + kk;
-                if (k > kmax) continue;
-                double ucur[NR]; const double ukk = dnext;
+            for (int kb = 60; kb >= 0; kb -= PD) {
 #pragma unroll
-                for (int k2 = 0; k2 < NR; ++k2) ucur[k2] = unext[k2];
-                {                                              // prefetch column k-1 (clamped at 0: harmless reload)
-                    const int kn = k > 0 ? k - 1 : 0;
-                    int sel = 0;
+                for (int e = PD - 1; e >= 0; --e) {
+                    const int k = 64 * q + kb + e;
+                    if (k <= kmax) {
+                        const double rukk = 1.0 / dq_[e];
+                        double xk[CW];
 #pragma unroll
-                    for (int q2 = 0; q2 < NR; ++q2) if (q2 == (kn >> 6)) sel = prow[q2];
-                    const int pkn = __builtin_amdgcn_readlane(sel, kn & 63);
-                    const long cb = colbase(kn, pkn);
-                    dnext = tri ? LU[kn + cb] : LU[pkn + cb];
+                        for (int cc = 0; cc < CW; ++cc) {
+                            const double v = readlane_f64(x[cc][q], kb + e) * rukk;
+                            xk[cc] = v;
+                            if (lane == kb + e) x[cc][q] = v;
+                        }
 #pragma unroll
-                    for (int k2 = 0; k2 < NR; ++k2) { const int r = lane + 64 * k2; const double v = LU[(tri ? min(r, n - 1) : prow[k2]) + cb]; unext[k2] = (r < kn) ? v : 0.0; }
-                }
-                const double rukk = 1.0 / ukk;
-                double xk[CW];
+                        for (int k2 = 0; k2 <= q; ++k2) {
 #pragma unroll
-                for (int cc = 0; cc < CW; ++cc) {
-                    const double v = readlane_f64(x[cc][q], kk) * rukk;
-                    xk[cc] = v;
-                    if (lane == kk) x[cc][q] = v;
-                }
-#pragma unroll
-                for (int k2 = 0; k2 <= q; ++k2) {
-#pragma unroll
-                    for (int cc = 0; cc < CW; ++cc) x[cc][k2] -= ucur[k2] * xk[cc];        // ucur is 0 for rows >= k
+                            for (int cc = 0; cc < CW; ++cc) x[cc][k2] -= uq[e][k2] * xk[cc];    // uq is 0 for rows >= k
+                        }
+                    }
+                    fetchU(e, k - PD);
                 }
             }
         }

@@ -171,58 +171,65 @@ __global__ __launch_bounds__(1024) void qrcp_kernel(Mat Am, QrWork w, int n) {
     }
 }
 
-// Each wave owns CW columns of Q in registers; applies H_i, i = n-1 .. 0.
-// Reflector i lives in column jpvt[i] of A (rows > i).
-template <int NR>
+// Q = H_0 ... H_{n-1} I, one COLUMN of Q per 16-lane DPP row: lane = 16*cq + rg holds rows 16*j + rg
+// (j < NRR) of column c0 + cq in registers, so the dot product of a reflector with a column is NRR FMAs
+// plus a 4-step DPP row reduction, and the four columns of a wave are processed at once (a full
+// 64-lane wave_sum per column made this kernel 6x slower).  Reflector i lives in column jpvt[i] of A
+// (rows > i); the next reflector is prefetched while the current one is applied.  Column tiles of Q are
+// independent: grid = (n/16 tiles) x chains, no LDS, no barriers.
+template <int NRR>
 __global__ __launch_bounds__(256) void formq_kernel(CMat Am, const double* tau_p, long tau_stride, const int* jpvt_p, long jpvt_stride, Mat Qm, int n) {
-    constexpr int CW = 4;
     const int chain = blockIdx.y;
     const double* __restrict__ A = Am.at(chain);
     const double* __restrict__ tau = tau_p + (long)chain * tau_stride;
     const int* __restrict__ jpvt = jpvt_p + (long)chain * jpvt_stride;
     double* __restrict__ Q = Qm.at(chain);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c0 = blockIdx.x * 16 + wave * CW;
-    if (c0 >= n) return;
-    double q[CW][NR];
+    const int rg = lane & 15, cq = lane >> 4;
+    const int c = blockIdx.x * 16 + wave * 4 + cq;             // my column
+    const int cw_max = min(blockIdx.x * 16 + wave * 4 + 3, n - 1);   // largest column of this wave
+    const bool wave_idle = blockIdx.x * 16 + wave * 4 >= n;
+    double q[NRR];
 #pragma unroll
-    for (int cc = 0; cc < CW; ++cc)
+    for (int j = 0; j < NRR; ++j) q[j] = (16 * j + rg == c) ? 1.0 : 0.0;
+    // three reflectors in flight; jpvt / tau are staged in LDS first: read from HBM inside the loop, the pivot
+    // index is a dependent load in front of every column fetch (one L2 latency per reflector whatever the depth)
+    __shared__ int s_jpvt[1024];
+    __shared__ double s_tau[1024];
+    for (int k = threadIdx.x; k < n; k += blockDim.x) { s_jpvt[k] = jpvt[k]; s_tau[k] = tau[k]; }
+    __syncthreads();
+    if (wave_idle) return;
+    constexpr int PD = 3;
+    double vq[PD][NRR]; double tq[PD];
+    auto fetch = [&](int slot, int ii) {
+        const int ic = ii > 0 ? ii : 0;                      // clamped: harmless reload past the end
+        const long cb = (long)n * s_jpvt[ic]; tq[slot] = s_tau[ic];
 #pragma unroll
-        for (int k = 0; k < NR; ++k) q[cc][k] = (lane + 64 * k == c0 + cc) ? 1.0 : 0.0;
-    const int cmax = min(c0 + CW - 1, n - 1);
-    // software prefetch of the next reflector hides the L2 latency of the serial chain
-    double vnext[NR]; double tnext = tau[cmax];
-    {
-        const int pc = jpvt[cmax];
+        for (int j = 0; j < NRR; ++j) { const int r = 16 * j + rg; const double x = A[min(r, n - 1) + cb]; vq[slot][j] = (r > ic && r < n) ? x : (r == ic ? 1.0 : 0.0); }
+    };
+    auto apply = [&](int slot, int i) {
+        const double ti = tq[slot];
+        if (ti == 0.0) return;
+        double s = 0.0;
 #pragma unroll
-        for (int k = 0; k < NR; ++k) { const int r = lane + 64 * k; vnext[k] = (r > cmax && r < n) ? A[r + (long)n * pc] : (r == cmax ? 1.0 : 0.0); }
+        for (int j = 0; j < NRR; ++j) s += vq[slot][j] * q[j];
+        s = row16_sum(s) * ti;
+        if (c < i) s = 0.0;                                  // column still e_c: untouched by H_i
+#pragma unroll
+        for (int j = 0; j < NRR; ++j) q[j] -= s * vq[slot][j];
+    };
+    fetch(0, cw_max); fetch(1, cw_max - 1); fetch(2, cw_max - 2);
+    int i = cw_max;
+    for (; i >= 2; i -= 3) {                                 // static slot indices: the ring is unrolled by hand
+        apply(0, i);     fetch(0, i - 3);
+        apply(1, i - 1); fetch(1, i - 4);
+        apply(2, i - 2); fetch(2, i - 5);
     }
-    for (int i = cmax; i >= 0; --i) {
-        double vr[NR]; const double ti = tnext;
+    if (i >= 0) apply(0, i);
+    if (i >= 1) apply(1, i - 1);
+    if (c < n) {
 #pragma unroll
-        for (int k = 0; k < NR; ++k) vr[k] = vnext[k];
-        if (i > 0) {
-            const int pc = jpvt[i - 1]; tnext = tau[i - 1];
-#pragma unroll
-            for (int k = 0; k < NR; ++k) { const int r = lane + 64 * k; vnext[k] = (r > i - 1 && r < n) ? A[r + (long)n * pc] : (r == i - 1 ? 1.0 : 0.0); }
-        }
-        if (ti == 0.0) continue;
-#pragma unroll
-        for (int cc = 0; cc < CW; ++cc) {
-            if (c0 + cc < i) continue;            // column still e_c: untouched by H_i
-            double s = 0.0;
-#pragma unroll
-            for (int k = 0; k < NR; ++k) s += vr[k] * q[cc][k];
-            s = wave_sum(s) * ti;
-#pragma unroll
-            for (int k = 0; k < NR; ++k) q[cc][k] -= s * vr[k];
-        }
-    }
-#pragma unroll
-    for (int cc = 0; cc < CW; ++cc) {
-        if (c0 + cc >= n) continue;
-#pragma unroll
-        for (int k = 0; k < NR; ++k) { const int r = lane + 64 * k; if (r < n) Q[r + (long)n * (c0 + cc)] = q[cc][k]; }
+        for (int j = 0; j < NRR; ++j) { const int r = 16 * j + rg; if (r < n) Q[r + (long)n * c] = q[j]; }
     }
 }
 
@@ -258,7 +265,7 @@ static int launch_to_ldr_nr(Mat A, Mat L, Vec d, Mat R, QrWork w, int n, int n_c
         static const bool use_coop = getenv("DQMC_QR_COOP") != nullptr;
         if (n > 128 && w.sync && use_coop && 8 * n_chains <= 2048) DQ_TRY_RC(launch_qrcp_coop(A, w, n, n_chains, s));
         else DQ_TRY_RC(launch_qrcp_onchip(A, w, n, n_chains, s));
-        hipLaunchKernelGGL((formq_kernel<NR>), dim3((n + 15) / 16, n_chains), dim3(256), 0, s, CMat(A), (const double*)w.tau, w.tau_stride,
+        hipLaunchKernelGGL((formq_kernel<4 * NR>), dim3((n + 15) / 16, n_chains), dim3(256), 0, s, CMat(A), (const double*)w.tau, w.tau_stride,
                            (const int*)w.jpvt, w.jpvt_stride, L, n);
         hipLaunchKernelGGL(assemble_r_kernel, dim3(n, n_chains), dim3(128), 0, s, CMat(A), (const int*)w.jpvt, w.jpvt_stride, d, R, n);
         DQ_HIP(hipGetLastError());
@@ -271,7 +278,7 @@ static int launch_to_ldr_nr(Mat A, Mat L, Vec d, Mat R, QrWork w, int n, int n_c
         attr_set = true;
     }
     hipLaunchKernelGGL((qrcp_kernel<NR>), dim3(1, n_chains), dim3(1024), lds, s, A, w, n);
-    hipLaunchKernelGGL((formq_kernel<NR>), dim3((n + 15) / 16, n_chains), dim3(256), 0, s, CMat(A), (const double*)w.tau, w.tau_stride,
+    hipLaunchKernelGGL((formq_kernel<4 * NR>), dim3((n + 15) / 16, n_chains), dim3(256), 0, s, CMat(A), (const double*)w.tau, w.tau_stride,
                        (const int*)w.jpvt, w.jpvt_stride, L, n);
     hipLaunchKernelGGL(assemble_r_kernel, dim3(n, n_chains), dim3(128), 0, s, CMat(A), (const int*)w.jpvt, w.jpvt_stride, d, R, n);
     DQ_HIP(hipGetLastError());

@@ -237,10 +237,11 @@ __global__ __launch_bounds__(MAXT) void scan_kernel(UpdateDesc d, int l, int acc
 }
 
 // G[a,b] += sum_{m<k} Up[m][a] * Wp[m][b];  one wave per 16x16 tile, 2x2 waves per block.
-__global__ __launch_bounds__(256) void flush_kernel(UpdateDesc d, int tiles_per_dim) {
+// Latency matters more than flops here (N x k x N with k <= 32): the window's pair count k, the G tile and the
+// panel rows are all loaded in ONE round trip (panel rows unconditionally for all KD slots -- stale slots are
+// masked after the fact), instead of k -> panels -> G one after the other.
+__global__ __launch_bounds__(256) void flush_kernel(UpdateDesc d, int tiles_per_dim, int kd) {
     const int chain = blockIdx.y;
-    const int k = d.state[(long)chain * d.state_stride + 1];
-    if (k == 0) return;
     const int n = d.n;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int a0 = (blockIdx.x % tiles_per_dim) * 32 + (wave & 1) * 16;
@@ -250,19 +251,30 @@ __global__ __launch_bounds__(256) void flush_kernel(UpdateDesc d, int tiles_per_
     const double* __restrict__ Wp = d.Wpanel + (long)chain * d.panel_stride;
     double* __restrict__ G = d.G.at(chain);
     const int r = lane & 15, kk = lane >> 4;
-    const int a = a0 + r, b = b0 + r;
-    d4 acc = {0.0, 0.0, 0.0, 0.0};
-    for (int m0 = 0; m0 < k; m0 += 4) {
-        const int m = m0 + kk;
-        const double wv = (m < k && b < n) ? Wp[(size_t)m * n + b] : 0.0;    // MFMA-A: rows <-> b
-        const double uv = (m < k && a < n) ? Up[(size_t)m * n + a] : 0.0;    // MFMA-B: cols <-> a
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wv, uv, acc, 0, 0, 0);
+    const int a = min(a0 + r, n - 1), b = min(b0 + r, n - 1);          // clamped: loads stay unconditional
+    const bool a_ok = a0 + r < n, b_ok = b0 + r < n;
+    const int k = d.state[(long)chain * d.state_stride + 1];
+    double uv[UPDATE_KD / 4], wv[UPDATE_KD / 4], gv[4];
+#pragma unroll
+    for (int s = 0; s < UPDATE_KD / 4; ++s) {
+        const int m = min(4 * s + kk, kd - 1);
+        wv[s] = Wp[m * n + b]; uv[s] = Up[m * n + a];
     }
-    if (a < n) {
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) { const int bb = min(b0 + kk + 4 * reg, n - 1); gv[reg] = G[a + (long)n * bb]; }
+    if (k == 0) return;
+    d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < UPDATE_KD / 4; ++s) {
+        const int m = 4 * s + kk;
+        const bool ok = m < k;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64((ok && b_ok) ? wv[s] : 0.0, (ok && a_ok) ? uv[s] : 0.0, acc, 0, 0, 0);   // A: rows <-> b, B: cols <-> a
+    }
+    if (a_ok) {
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
             const int bb = b0 + kk + 4 * reg;
-            if (bb < n) G[a + (long)n * bb] += acc[reg];
+            if (bb < n) G[a + (long)n * bb] = gv[reg] + acc[reg];
         }
     }
 }
@@ -293,7 +305,7 @@ int launch_update_slice(const UpdateDesc& d, int l, int acc_slot, int n_chains, 
     for (int w = 0; w < windows; ++w) {
         if (threads <= 256) hipLaunchKernelGGL(scan_kernel<256>, dim3(1, n_chains), dim3(threads), lds, s, d, l, acc_slot, w == 0 ? 1 : 0, kd);
         else hipLaunchKernelGGL(scan_kernel<1024>, dim3(1, n_chains), dim3(threads), lds, s, d, l, acc_slot, w == 0 ? 1 : 0, kd);
-        hipLaunchKernelGGL(flush_kernel, dim3(tiles * tiles, n_chains), dim3(256), 0, s, d, tiles);
+        hipLaunchKernelGGL(flush_kernel, dim3(tiles * tiles, n_chains), dim3(256), 0, s, d, tiles, kd);
     }
     DQ_HIP(hipGetLastError());
     return 0;
