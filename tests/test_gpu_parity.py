@@ -318,6 +318,58 @@ def test_large_batch_uses_throughput_gemm(hip, orc):
         assert st[c].n_accepted == o.stats().n_accepted
 
 
+@pytest.mark.parametrize("L,nt,n_stab", [(2, 10, 10), (2, 7, 3), (4, 5, 10), (3, 12, 4)])
+def test_small_and_odd_shapes(hip, orc, L, nt, n_stab):
+    """Edge shapes: 2x2 lattice (K uses assignment, not +=: source/model.cpp:43-58), n_stab > nt (one short block),
+    nt not a multiple of n_stab, odd N (9 sites)."""
+    m = HubbardModel(L1=L, L2=L, U=4.0, beta=1.0, nt=nt, n_stab=n_stab); f = m.random_fields(3)
+    e = m.engine(hip); e.set_fields(f); e.init(); o = m.engine(orc); o.set_fields(f); o.init()
+    assert e.n_stack() == o.n_stack() == -(-nt // n_stab)
+    assert close(e.get_G(), o.get_G())
+    rng = np.random.default_rng(5)
+    for _ in range(2):
+        s1, s2 = m.random_stream(rng), m.random_stream(rng)
+        e.sweep_0_to_beta(*s1); e.sweep_beta_to_0(*s2); o.sweep_0_to_beta(*s1); o.sweep_beta_to_0(*s2)
+        assert (e.get_fields() == o.get_fields()).all() and close(e.get_G(), o.get_G())
+    assert e.stats().n_err == o.stats().n_err and e.stats().n_accepted == o.stats().n_accepted
+
+
+def test_set_G_and_reinit_are_consistent(hip, orc):
+    """dqmc_set_G / dqmc_get_G round trip; re-running init after a sweep (what replica exchange does,
+    source/update.cpp:77-80) reproduces the from-scratch G of the current fields."""
+    m = HubbardModel(**CONFIGS["cfg2"]); f = m.random_fields(31)
+    e = m.engine(hip); e.set_fields(f); e.init()
+    G = e.get_G(); e.set_G(2.0 * G); assert np.array_equal(e.get_G(), 2.0 * G); e.set_G(G)
+    rng = np.random.default_rng(2)
+    e.sweep_0_to_beta(*m.random_stream(rng)); e.sweep_beta_to_0(*m.random_stream(rng))
+    G1 = e.get_G(); S1 = e.global_action(); f1 = e.get_fields()
+    e.init()                                       # same fields, stacks rebuilt from scratch
+    assert close(e.get_G(), G1, 1e-9) and abs(e.global_action() - S1) < 1e-7 * abs(S1)
+    o = m.engine(orc); o.set_fields(f1); o.init()
+    assert close(e.get_G(), o.get_G()) and abs(e.global_action() - o.global_action()) < 1e-8 * abs(S1)
+
+
+def test_alternative_kernel_paths_in_subprocess(hip):
+    """The opt-in / fallback kernels (cooperative 8-workgroup QRCP, streaming QRCP, streaming LU, one-wave-per-tile GEMM)
+    are selected by environment switches read once per process: run them in child processes and check cfg-3 init parity
+    against the default path (itself checked against the oracle above)."""
+    import subprocess, sys, json
+    code = ("import sys, json, numpy as np; sys.path.insert(0, %r); import dqmc_amd; "
+            "m = dqmc_amd.HubbardModel(**dqmc_amd.CONFIGS['cfg3']); e = m.engine(dqmc_amd.lib()); "
+            "e.set_fields(m.random_fields(12)); e.init(); G = e.get_G(); "
+            "print(json.dumps({'ld': e.get_logdet(), 'g00': float(G[0, 0]), 'sum': float(np.abs(G).sum())}))") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    def run(env_extra):
+        env = dict(os.environ); env.update(env_extra)
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return json.loads(out.stdout.strip().splitlines()[-1])
+    ref = run({})
+    for env in ({"DQMC_QR_COOP": "1"}, {"DQMC_QR_STREAMING": "1"}, {"DQMC_LU_STREAMING": "1"}, {"DQMC_GEMM_V1": "1"}):
+        got = run(env)
+        assert abs(got["ld"] - ref["ld"]) < 1e-8 * abs(ref["ld"]), (env, got, ref)
+        assert abs(got["sum"] - ref["sum"]) < 1e-7 * abs(ref["sum"]), (env, got, ref)
+
+
 def test_error_codes(hip):
     from dqmc_amd import DqmcError
     m = HubbardModel(**CONFIGS["cfg1"]); e = m.engine(hip); e.set_fields(m.random_fields(1))
