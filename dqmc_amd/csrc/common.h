@@ -130,6 +130,9 @@ struct UpdateDesc {
     double* Upanel; double* Wpanel; long panel_stride;   // [chain][KD][n]
     int* state; long state_stride;            // per chain: [0]=pos, [1]=k (accepts in current window), [2]=accepted in slice
     double* prep; long prep_stride;           // per chain 4*n doubles: the slice's G-independent proposal data
+    Mat GT{nullptr, 0};                       // transposed copy of G the n <= 256 walk reads rows from (workspace; rebuilt at every slice)
+    void* slice_sync = nullptr;               // per chain 64 zeroed bytes: hand-off words of the persistent slice kernel (null -> multi-kernel path)
+    int* info = nullptr;                      // |= 4 when a hand-off of the persistent slice kernel timed out
     int* acc_out; long acc_stride;            // per chain per slice accepted counts [chain][2*nt] (+ offset chosen by caller)
     int n, nt;
 };

@@ -170,7 +170,7 @@ struct Engine {
     int8_t* fields = nullptr;                                    // [C][nt][n]
     double* expv = nullptr; double* invexpv = nullptr;           // [C][nt][n]
     UpdateTables* tabs = nullptr; double* tab8 = nullptr;        // [C], [C][8]
-    double* G = nullptr; double* Gtmp = nullptr;                 // [C][nn]
+    double* G = nullptr; double* Gtmp = nullptr; double* GT = nullptr;   // [C][nn]; GT: transposed copy for the local-update walk
     double* bb0 = nullptr; double* bb1 = nullptr;                // Bbar ping-pong
     double* stackL = nullptr; double* stackD = nullptr; double* stackR = nullptr;
     double* tmpL = nullptr; double* tmpD = nullptr; double* tmpR = nullptr;   // one spare LDR (init_stacks)
@@ -183,6 +183,7 @@ struct Engine {
     double* Upanel = nullptr; double* Wpanel = nullptr;          // [C][KD][n]
     int* state = nullptr;                                        // [C][4]
     double* prep = nullptr;                                      // [C][4n]
+    char* slice_sync = nullptr;                                  // [C][64 B] hand-off words of the persistent slice kernel
     int* acc = nullptr;                                          // [C][nt]
     double* err = nullptr;                                       // [C][n_stack]
     DevStats* dstats = nullptr;                                  // [C]
@@ -208,7 +209,7 @@ struct Engine {
         if (s) (void)hipStreamSynchronize(s);
         for (auto& p : ev_pairs) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
         if (stage_free) (void)hipEventDestroy(stage_free);
-        void* ptrs[] = {prep, stackP, expK, invexpK, fields, expv, invexpv, tabs, tab8, G, Gtmp, bb0, bb1, stackL, stackD, stackR, tmpL, tmpD, tmpR,
+        void* ptrs[] = {GT, slice_sync, prep, stackP, expK, invexpK, fields, expv, invexpv, tabs, tab8, G, Gtmp, bb0, bb1, stackL, stackD, stackR, tmpL, tmpD, tmpR,
                         logdet, rs_perm, rs_k, rs_u, Upanel, Wpanel, state, acc, err, dstats, r1scratch};
         for (void* p : ptrs) if (p) (void)hipFree(p);
         if (h_stage) (void)hipHostFree(h_stage);
@@ -227,14 +228,14 @@ struct Engine {
         DQ_TRY(dalloc(&expK, C * nn)); DQ_TRY(dalloc(&invexpK, C * nn));
         DQ_TRY(dalloc(&fields, (size_t)C * nt * n)); DQ_TRY(dalloc(&expv, (size_t)C * nt * n)); DQ_TRY(dalloc(&invexpv, (size_t)C * nt * n));
         DQ_TRY(dalloc(&tabs, C)); DQ_TRY(dalloc(&tab8, (size_t)C * 8));
-        DQ_TRY(dalloc(&G, C * nn)); DQ_TRY(dalloc(&Gtmp, C * nn)); DQ_TRY(dalloc(&bb0, C * nn)); DQ_TRY(dalloc(&bb1, C * nn));
+        DQ_TRY(dalloc(&G, C * nn)); DQ_TRY(dalloc(&Gtmp, C * nn)); DQ_TRY(dalloc(&GT, C * nn)); DQ_TRY(dalloc(&bb0, C * nn)); DQ_TRY(dalloc(&bb1, C * nn));
         DQ_TRY(dalloc(&stackL, (size_t)n_stack * C * nn)); DQ_TRY(dalloc(&stackD, (size_t)n_stack * C * n)); DQ_TRY(dalloc(&stackR, (size_t)n_stack * C * nn));
         DQ_TRY(dalloc(&stackP, (size_t)n_stack * C * n)); stack_tri.reset(new bool[n_stack]());
         DQ_TRY(dalloc(&tmpL, C * nn)); DQ_TRY(dalloc(&tmpD, (size_t)C * n)); DQ_TRY(dalloc(&tmpR, C * nn));
         DQ_TRY(dalloc(&logdet, C));
         DQ_TRY(dalloc(&rs_perm, (size_t)C * nt * n)); DQ_TRY(dalloc(&rs_k, (size_t)C * nt * n)); DQ_TRY(dalloc(&rs_u, (size_t)C * nt * n));
         DQ_TRY(dalloc(&Upanel, (size_t)C * UPDATE_KD * n)); DQ_TRY(dalloc(&Wpanel, (size_t)C * UPDATE_KD * n));
-        DQ_TRY(dalloc(&state, (size_t)C * 4)); DQ_TRY(dalloc(&prep, (size_t)C * 4 * n)); DQ_TRY(dalloc(&acc, (size_t)C * nt)); DQ_TRY(dalloc(&err, (size_t)C * n_stack));
+        DQ_TRY(dalloc(&state, (size_t)C * 4)); DQ_TRY(dalloc(&prep, (size_t)C * 4 * n)); DQ_TRY(dalloc(&slice_sync, (size_t)C * 64)); DQ_HIP(hipMemsetAsync(slice_sync, 0, (size_t)C * 64, s)); DQ_TRY(dalloc(&acc, (size_t)C * nt)); DQ_TRY(dalloc(&err, (size_t)C * n_stack));
         DQ_TRY(dalloc(&dstats, C)); DQ_TRY(dalloc(&r1scratch, (size_t)C * (2 * n + 1)));
         h_stage_bytes = (size_t)C * nt * n * (sizeof(int32_t) + sizeof(uint8_t) + sizeof(double));
         DQ_HIP(hipHostMalloc(&h_stage, h_stage_bytes, hipHostMallocDefault));
@@ -305,7 +306,7 @@ struct Engine {
     UpdateDesc udesc() const {
         UpdateDesc d; d.G = mG(); d.fields = fields; d.f_stride = (long)nt * n; d.expv = expv; d.invexpv = invexpv; d.v_stride = (long)nt * n;
         d.tabs = tabs; d.perm = rs_perm; d.kprop = rs_k; d.u = rs_u; d.rs_stride = (long)nt * n; d.Upanel = Upanel; d.Wpanel = Wpanel;
-        d.panel_stride = (long)UPDATE_KD * n; d.state = state; d.state_stride = 4; d.prep = prep; d.prep_stride = 4L * n; d.acc_out = acc; d.acc_stride = nt; d.n = n; d.nt = nt;
+        d.panel_stride = (long)UPDATE_KD * n; d.state = state; d.state_stride = 4; d.prep = prep; d.prep_stride = 4L * n; d.slice_sync = slice_sync; d.GT = Mat{GT, nn}; d.info = ctx.info(); d.acc_out = acc; d.acc_stride = nt; d.n = n; d.nt = nt;
         return d;
     }
     int local_update(int l) {
@@ -381,6 +382,7 @@ struct Engine {
         }
         int h_info = 0;
         DQ_HIP(hipMemcpy(&h_info, ctx.info(), sizeof(int), hipMemcpyDeviceToHost));
+        if (h_info & 4) { set_error("persistent slice kernel: a hand-off timed out (workgroups not co-resident?)"); (void)hipMemset(ctx.info(), 0, sizeof(int)); (void)hipMemset(slice_sync, 0, (size_t)C * 64); return DQMC_ENUMERIC; }
         if (h_info & 2) { set_error("cooperative QRCP gave up waiting for a partner workgroup (not co-resident?)"); (void)hipMemset(ctx.info(), 0, sizeof(int)); return DQMC_ENUMERIC; }
         if (h_info) { set_error("LU factorisation hit a zero or NaN pivot"); (void)hipMemset(ctx.info(), 0, sizeof(int)); return DQMC_ENUMERIC; }
         return 0;

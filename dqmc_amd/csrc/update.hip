@@ -21,6 +21,8 @@
 // A slice is ceil(N/KD) (scan, flush) pairs; pairs past the end of the walk
 // find pos == N / k == 0 and exit immediately.
 #include "common.h"
+#include <cstdlib>
+#include "wave.h"
 
 namespace dq {
 
@@ -38,11 +40,40 @@ __constant__ int c_proposal[4][3] = {{1, 2, 3}, {0, 2, 3}, {0, 1, 3}, {0, 1, 2}}
 // ends up accepted: G in HBM/L2 does not change inside a window, so the prefetch is exact.
 constexpr int SCAN_PF = 8;
 
+// agent-scope relaxed accesses (sc1 on gfx950: bypass the CU's L1, write through): what the persistent
+// slice kernel uses for every word another workgroup of the same launch writes or reads
+__device__ __forceinline__ double ld_coh(const double* p) {
+    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void st_coh(double* p, double x) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// bytes of dynamic LDS: UW[kd][n] | diag, dlt, rbv, ur [n] | tables[32] | site[n] | newf[n] (padded) | (register variant) diag2[n]
+__host__ __device__ inline size_t scan_lds_bytes(int n, int kd, bool regs) {
+    const size_t base = (((size_t)16 * kd * n + (size_t)n * 32 + 256 + (size_t)n * 4 + (size_t)n) + 63) & ~(size_t)63;
+    return base + (regs ? (size_t)n * 8 + 4 * UPDATE_KD : 0);
+}
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a workgroup-scope release fence, which on
+// gfx950 is s_waitcnt vmcnt(0): every barrier of the walk would wait for the panel stores just issued (~500-1000
+// clk to L2 / memory) and for the G prefetch of the NEXT groups, i.e. the prefetch could never run ahead (measured:
+// tail 550 -> 1100 clk per accepted flip once it became the only barrier).  Global data written in the walk is
+// consumed by other kernels / other workgroups after an explicit vmcnt(0), never by this workgroup through memory.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 struct ScanShared {
     double2* UW; double* diag; double* dlt; double* rbv; double* ur; double* tl; int* site; signed char* newf;
+    double* diag2 = nullptr;      // walk v3 only: second diagonal buffer
+    int* acc_site = nullptr;      // walk v3 only: proposal index of pending pair m (KD entries)
 };
 
 // loads G[:, site] / G[site, :] elements of thread j for the SCAN_PF proposals of group g
+template <bool COH>
 __device__ __forceinline__ void scan_prefetch(double (&pc)[SCAN_PF], double (&pr)[SCAN_PF], const double* __restrict__ G, const ScanShared& sh,
                                               int g, int n, int j, bool live) {
 #pragma unroll
@@ -52,7 +83,8 @@ __device__ __forceinline__ void scan_prefetch(double (&pc)[SCAN_PF], double (&pr
         const int pos = min(g * SCAN_PF + q, n - 1);
         const int jj = live ? j : n - 1;
         const int i = sh.site[pos];
-        pc[q] = G[jj + (long)n * i]; pr[q] = G[i + (long)n * jj];
+        if (COH) { pc[q] = ld_coh(G + jj + (long)n * i); pr[q] = ld_coh(G + i + (long)n * jj); }
+        else { pc[q] = G[jj + (long)n * i]; pr[q] = G[i + (long)n * jj]; }
     }
 }
 
@@ -64,6 +96,7 @@ struct ScanProf { unsigned long long t_rej = 0, t_kloop = 0, t_tail = 0, t_wait 
 #else
 #define PROF_ARG
 #endif
+template <bool COH>
 __device__ __forceinline__ bool scan_group(const double (&pc)[SCAN_PF], const double (&pr)[SCAN_PF], const ScanShared& sh, int g, int n, int kd,
                                            int j, bool live, int& pos, int& k, const UpdateDesc& d, long slice_off, int chain, int8_t* fields_g,
                                            double* __restrict__ Up, double* __restrict__ Wp PROF_ARG) {
@@ -125,12 +158,13 @@ __device__ __forceinline__ bool scan_group(const double (&pc)[SCAN_PF], const do
 #ifdef DQ_SCAN_STAMPS
             STAMP(t2)
 #endif
-            __syncthreads();                                      // every lane has read diag[i] and the pivot entries
+            lds_barrier();                                      // every lane has read diag[i] and the pivot entries
             if (live) {
                 const double pu = pref * uj;
                 sh.UW[k * n + j] = make_double2(pu, wj);
                 sh.diag[j] += pu * wj;
-                Up[k * n + j] = pu; Wp[k * n + j] = wj;         // the flush kernel's operands, stored as we go (fire and forget)
+                if (COH) { st_coh(Up + k * n + j, pu); st_coh(Wp + k * n + j, wj); }
+                else { Up[k * n + j] = pu; Wp[k * n + j] = wj; }    // the flush kernel's operands, stored as we go (fire and forget)
                 if (j == i) {
                     const int new_f = sh.newf[mypos];
                     fields_g[i] = (int8_t)new_f;                  // field.set_single_field (source/update.cpp:28)
@@ -139,7 +173,7 @@ __device__ __forceinline__ bool scan_group(const double (&pc)[SCAN_PF], const do
                 }
             }
             ++k;
-            __syncthreads();
+            lds_barrier();
 #ifdef DQ_SCAN_STAMPS
             STAMP(t3) prof.t_wait += t1 - t0; prof.t_kloop += t2 - t1; prof.t_tail += t3 - t2; prof.n_acc++;
         } else { STAMP(t1) prof.t_rej += t1 - t0; prof.n_rej++;
@@ -150,9 +184,209 @@ __device__ __forceinline__ bool scan_group(const double (&pc)[SCAN_PF], const do
     return true;
 }
 
+
+// ---- walk v3 (n <= 256: one wave per SIMD, 512 VGPRs per lane) ------------------------------------------------------
+// What the stamps of the LDS variant above showed, per accepted flip at the average k = 16 (cycles):
+//   ~1250 pending-pair loop: LDS-bandwidth bound (each lane reads its own pairs AND the pivot's pairs; a broadcast
+//         read still occupies the pipe for 64 lanes x 16 B: 4 waves x 2k reads x 8 clk),
+//   ~ 550 two barriers, each a vmcnt(0) because __syncthreads() is a release fence and the panel rows were stored to
+//         HBM as they were produced -- and stores in flight also forbid partial vmcnt waits on the prefetch loads,
+//   ~ 200 per proposal for the serial decision chain (site -> diag -> ratio), rejected ones included,
+//   and the row prefetch G[site, :] touches one 128-B line per lane (the whole of G every 16 proposals).
+// This variant therefore
+//   * keeps a lane's own pending pairs {U_m[j], W_m[j]} in REGISTERS (vector types, so that the slot written per
+//     accepted flip is a wave-uniform s_set_gpr_idx move, not a scratch array),
+//   * fetches the pivot's pairs {U_m[i], W_m[i]} with two compact LDS reads per wave (lane r of every 16-lane row
+//     holds pairs r and 16 + r) and feeds them to the FMAs straight from the DPP network
+//     (v_fmac_f64_dpp row_newbcast:r -- CDNA's only 64-bit DPP mode), no readlane / SGPR round trip,
+//   * evaluates the Metropolis decision for the next 64 proposals at once (lane t <-> proposal pos + t) and jumps
+//     to the first accepted one: decisions after it are discarded because the diagonal changes, rejected ones before
+//     it are exact, so the cost per accepted flip no longer depends on how many rejections lie in between,
+//   * issues NO global store inside the walk: panel rows, fields and exp(V) entries are written when the window
+//     closes (from registers / a 32-entry LDS list); barriers order LDS only,
+//   * reads the row G[site, :] from a transposed copy GT that the flush keeps in step with G (coalesced),
+//   * double-buffers the diagonal in LDS (one barrier per accepted flip instead of two).
+typedef double d16v __attribute__((ext_vector_type(16)));
+
+// Compiler note: the register-resident vectors must be LOCAL variables, handed to helpers by value and returned by
+// value.  Taken by reference (or as members of a struct passed by reference) their dynamically indexed element
+// accesses become variable GEPs into an alloca that SROA cannot promote, and the whole set lands in scratch.
+
+// G[j, site] (pc) and G[site, j] (pr, read from the transposed copy) of the 8 proposals of group g.  Plain arrays with
+// compile-time indices only: they may live in AGPRs (the 256 architectural VGPRs are taken by the pending pairs).
+template <bool COH>
+__device__ __forceinline__ void walk_load_group(double (&pc)[8], double (&pr)[8], const double* __restrict__ G, const double* __restrict__ GT,
+                                                const ScanShared& sh, int g, int n, int j, bool live) {
+    const int jj = live ? j : n - 1;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int i = sh.site[min(g * 8 + q, n - 1)];             // clamped: loads stay unconditional
+        const long off = jj + (long)n * i;
+        if (COH) { pc[q] = ld_coh(G + off); pr[q] = ld_coh(GT + off); }
+        else { pc[q] = G[off]; pr[q] = GT[off]; }
+    }
+}
+__device__ __forceinline__ d16v vec_set(d16v v, int q, double x) { v[q] = x; return v; }
+
+#define DQ_PICK8(PC, PR)                                                                                            \
+    switch (first) {                                                                                                \
+        case 0: uj = PC[0]; wj = PR[0]; break; case 1: uj = PC[1]; wj = PR[1]; break;                               \
+        case 2: uj = PC[2]; wj = PR[2]; break; case 3: uj = PC[3]; wj = PR[3]; break;                               \
+        case 4: uj = PC[4]; wj = PR[4]; break; case 5: uj = PC[5]; wj = PR[5]; break;                               \
+        case 6: uj = PC[6]; wj = PR[6]; break; default: uj = PC[7]; wj = PR[7]; break;                              \
+    }
+
+// four pending pairs m = MB .. MB+3 of one 16-slot half: acc_u += own_u[m] * W_m[i], acc_w += U_m[i] * own_w[m], the pivot
+// values taken from lane m of each 16-lane row.  One asm block: the compiler's hazard recogniser does not look inside
+// inline asm, so the block opens with the wait states a DPP read of a just-written VGPR needs.
+#define DQ_FMAC4(R0, R1, R2, R3, ua, wa, ub, wb, pvx, pvy, OU, OW, MB)                                                                    \
+    asm("s_nop 1\n\t"                                                                                                                     \
+        "v_fmac_f64_dpp %0, %5, %6 row_newbcast:" #R0 " row_mask:0xf bank_mask:0xf\n\t"                                                   \
+        "v_fmac_f64_dpp %1, %4, %7 row_newbcast:" #R0 " row_mask:0xf bank_mask:0xf\n\t"                                                   \
+        "v_fmac_f64_dpp %2, %5, %8 row_newbcast:" #R1 " row_mask:0xf bank_mask:0xf\n\t"                                                   \
+        "v_fmac_f64_dpp %3, %4, %9 row_newbcast:" #R1 " row_mask:0xf bank_mask:0xf\n\t"                                                   \
+        "v_fmac_f64_dpp %0, %5, %10 row_newbcast:" #R2 " row_mask:0xf bank_mask:0xf\n\t"                                                  \
+        "v_fmac_f64_dpp %1, %4, %11 row_newbcast:" #R2 " row_mask:0xf bank_mask:0xf\n\t"                                                  \
+        "v_fmac_f64_dpp %2, %5, %12 row_newbcast:" #R3 " row_mask:0xf bank_mask:0xf\n\t"                                                  \
+        "v_fmac_f64_dpp %3, %4, %13 row_newbcast:" #R3 " row_mask:0xf bank_mask:0xf"                                                      \
+        : "+v"(ua), "+v"(wa), "+v"(ub), "+v"(wb)                                                                                          \
+        : "v"(pvx), "v"(pvy), "v"(OU[MB]), "v"(OW[MB]), "v"(OU[MB + 1]), "v"(OW[MB + 1]), "v"(OU[MB + 2]), "v"(OW[MB + 2]), "v"(OU[MB + 3]),    \
+          "v"(OW[MB + 3]))
+
+// Walks one window: from proposal `pos` until KD flips are pending or the slice is over, then writes the window's
+// panel rows (the flush's operands) and field changes to memory.  Returns the number of flips.
+//   dg: the lane's own diagonal entry (sh.diag holds the diagonal on entry)
+// Proposals are handled in groups of 8 with three register sets used round-robin (the group loop is unrolled by 3 so
+// that every set is addressed statically): while group g is walked, the G column / row elements of groups g + 1 and
+// g + 2 are in flight, and nothing but those loads is outstanding, so the wait before a group is a partial vmcnt.
+template <bool COH>
+__device__ __forceinline__ int walk_window(const ScanShared& sh, int& pos, double dg, int n, int kd, int j, bool live, const double* __restrict__ G,
+                                           const double* __restrict__ GT, const UpdateDesc& d, long slice_off, int chain, int8_t* fields_g,
+                                           double* __restrict__ Up, double* __restrict__ Wp PROF_ARG) {
+    const int lane = threadIdx.x & 63, r16 = lane & 15, q8 = lane & 7;
+    d16v ou0, ou1, ow0, ow1;                                      // own pending pairs: U_m[j], W_m[j] for m < 16 | m >= 16
+    double pc0[8], pr0[8], pc1[8], pr1[8], pc2[8], pr2[8];        // prefetched G column / row elements of group (g % 3)
+#pragma unroll
+    for (int m = 0; m < 16; ++m) { ou0[m] = 0.0; ou1[m] = 0.0; ow0[m] = 0.0; ow1[m] = 0.0; }
+    int par = 0, k = 0;
+    int g = pos >> 3;
+    bool done = false;
+    // sets of groups g and g + 1 (the group macro below requests g + 2 when it starts on g)
+    switch (g % 3) {
+        case 0: walk_load_group<COH>(pc0, pr0, G, GT, sh, g, n, j, live); walk_load_group<COH>(pc1, pr1, G, GT, sh, g + 1, n, j, live); break;
+        case 1: walk_load_group<COH>(pc1, pr1, G, GT, sh, g, n, j, live); walk_load_group<COH>(pc2, pr2, G, GT, sh, g + 1, n, j, live); break;
+        default: walk_load_group<COH>(pc2, pr2, G, GT, sh, g, n, j, live); walk_load_group<COH>(pc0, pr0, G, GT, sh, g + 1, n, j, live); break;
+    }
+#ifdef DQ_SCAN_STAMPS
+#define DQ_ST(...) __VA_ARGS__
+#else
+#define DQ_ST(...)
+#endif
+#define DQ_GROUP(PCS, PRS, PCT, PRT)                                                                                                     \
+    {                                                                                                                                    \
+        walk_load_group<COH>(PCT, PRT, G, GT, sh, g + 2, n, j, live);                                                                    \
+        const int gbase = g * 8;                                                                                                         \
+        for (;;) {                                                                                                                       \
+            DQ_ST(unsigned long long t0, t1, t2, t3; STAMP(t0))                                                                          \
+            /* decisions for the (remaining) proposals of the group under the current diagonal: lane q <-> proposal gbase + q */         \
+            const int p_l = gbase + q8, pc_l = min(p_l, n - 1);                                                                          \
+            const int i_l = sh.site[pc_l];                                                                                               \
+            const double dl_l = sh.dlt[pc_l];                                                                                            \
+            const double* dcur = par ? sh.diag2 : sh.diag;                                                                               \
+            const double r_l = 1.0 + (1.0 - dcur[i_l]) * dl_l;                 /* det ratio per flavour (source/model.cpp:95) */          \
+            const double R_l = sh.rbv[pc_l] * (r_l * r_l);                      /* :121 */                                               \
+            /* bernoulli(min(1,|R|)): u < p (source/update.cpp:24, include/utility.h:34-37) */                                           \
+            const bool acc_l = p_l >= pos && p_l < n && sh.ur[pc_l] < fmin(1.0, fabs(R_l));                                              \
+            const unsigned bal = (unsigned)__ballot(acc_l) & 0xffu;                                                                      \
+            if (bal == 0u) { pos = min(gbase + 8, n); break; }                  /* the rest of the group is rejected */                  \
+            const int first = __ffs((int)bal) - 1;                                                                                       \
+            const int p = gbase + first;                                                                                                 \
+            pos = p + 1;                                                                                                                 \
+            const int i = __builtin_amdgcn_readlane(i_l, first);                                                                         \
+            const double delta = readlane_f64(dl_l, first), r = readlane_f64(r_l, first);                                                \
+            const double pref = delta / r;                                      /* source/model.cpp:132 */                               \
+            /* pivot pairs: lane r16 of every row holds {U_m[i], W_m[i]} for m = r16 (pa) and m = 16 + r16 (pb) */                        \
+            const int kc = max(k - 1, 0);                                                                                                \
+            double2 pa = sh.UW[min(r16, kc) * n + i], pb = sh.UW[min(16 + r16, kc) * n + i];                                             \
+            if (r16 >= k) { pa.x = 0.0; pa.y = 0.0; }                                                                                    \
+            if (16 + r16 >= k) { pb.x = 0.0; pb.y = 0.0; }                                                                               \
+            double uj, wj;                                                                                                               \
+            DQ_PICK8(PCS, PRS)                                                                                                           \
+            DQ_ST(STAMP(t1))                                                                                                             \
+            /* G_eff[:, i], G_eff[i, :]: 2k FMAs per lane, pivot operand broadcast by DPP */                                             \
+            double u1 = 0.0, w1 = 0.0;                                                                                                   \
+            if (k > 0) {                                                                                                                 \
+                DQ_FMAC4(0, 1, 2, 3, uj, wj, u1, w1, pa.x, pa.y, ou0, ow0, 0);                                                           \
+                if (k > 4) DQ_FMAC4(4, 5, 6, 7, uj, wj, u1, w1, pa.x, pa.y, ou0, ow0, 4);                                                \
+                if (k > 8) DQ_FMAC4(8, 9, 10, 11, uj, wj, u1, w1, pa.x, pa.y, ou0, ow0, 8);                                              \
+                if (k > 12) DQ_FMAC4(12, 13, 14, 15, uj, wj, u1, w1, pa.x, pa.y, ou0, ow0, 12);                                          \
+                if (k > 16) DQ_FMAC4(0, 1, 2, 3, uj, wj, u1, w1, pb.x, pb.y, ou1, ow1, 0);                                               \
+                if (k > 20) DQ_FMAC4(4, 5, 6, 7, uj, wj, u1, w1, pb.x, pb.y, ou1, ow1, 4);                                               \
+                if (k > 24) DQ_FMAC4(8, 9, 10, 11, uj, wj, u1, w1, pb.x, pb.y, ou1, ow1, 8);                                             \
+                if (k > 28) DQ_FMAC4(12, 13, 14, 15, uj, wj, u1, w1, pb.x, pb.y, ou1, ow1, 12);                                          \
+            }                                                                                                                            \
+            uj += u1; wj += w1;                                                                                                          \
+            if (j == i) wj -= 1.0;                                              /* V(i) -= 1 (source/model.cpp:135) */                   \
+            const double pu = pref * uj;                                                                                                 \
+            DQ_ST(STAMP(t2))                                                                                                             \
+            dg += pu * wj;                                                                                                               \
+            if (live) {                                                                                                                  \
+                sh.UW[k * n + j] = make_double2(pu, wj);                        /* slot k: read by nobody before the barrier below */    \
+                (par ? sh.diag : sh.diag2)[j] = dg;                             /* the buffer no wave is reading */                      \
+            }                                                                                                                            \
+            if (j == 0) sh.acc_site[k] = p;                                     /* fields are written at window end */                   \
+            const int ks = k & 15;                                                                                                       \
+            if (k < 16) { ou0 = vec_set(ou0, ks, pu); ow0 = vec_set(ow0, ks, wj); } else { ou1 = vec_set(ou1, ks, pu); ow1 = vec_set(ow1, ks, wj); } \
+            ++k; par ^= 1;                                                                                                               \
+            lds_barrier();                                                                                                               \
+            DQ_ST(STAMP(t3) prof.t_wait += t1 - t0; prof.t_kloop += t2 - t1; prof.t_tail += t3 - t2; prof.n_acc++;)                      \
+            if (k >= kd) { done = true; break; }                                                                                         \
+        }                                                                                                                                \
+        if (pos >= n) done = true;                                                                                                       \
+        ++g;                                                                                                                             \
+    }
+    while (!done) {
+        switch (g % 3) {
+            case 0: DQ_GROUP(pc0, pr0, pc2, pr2) if (done) break; [[fallthrough]];
+            case 1: DQ_GROUP(pc1, pr1, pc0, pr0) if (done) break; [[fallthrough]];
+            default: DQ_GROUP(pc2, pr2, pc1, pr1) break;
+        }
+    }
+#undef DQ_GROUP
+#undef DQ_ST
+    // ---- window end: the flush's operands and the accepted field changes leave the workgroup (coalesced, from registers) ----
+    if (live) {
+#define DQ_DUMP(OU, OW, M, BASE)                                                                       \
+        if (COH) { st_coh(Up + (BASE + M) * n + j, OU[M]); st_coh(Wp + (BASE + M) * n + j, OW[M]); }   \
+        else { Up[(BASE + M) * n + j] = OU[M]; Wp[(BASE + M) * n + j] = OW[M]; }
+#pragma unroll
+        for (int m = 0; m < 16; ++m) { if (m >= k) break; DQ_DUMP(ou0, ow0, m, 0) }
+#pragma unroll
+        for (int m = 0; m < 16; ++m) { if (16 + m >= k) break; DQ_DUMP(ou1, ow1, m, 16) }
+#undef DQ_DUMP
+    }
+    if (j < k) {
+        const int p = sh.acc_site[j];
+        const int i = sh.site[p], new_f = sh.newf[p];
+        fields_g[i] = (int8_t)new_f;                                        // field.set_single_field (source/update.cpp:28)
+        d.expv[(long)chain * d.v_stride + slice_off + i] = sh.tl[24 + new_f];
+        d.invexpv[(long)chain * d.v_stride + slice_off + i] = sh.tl[28 + new_f];
+    }
+    return k;
+}
+static_assert(UPDATE_KD == 32, "walk v3 keeps 2 x 16 pending pairs per lane in registers");
+
+__device__ __forceinline__ void scan_shared_init(ScanShared& sh, unsigned char* smem, int n, int kd, bool regs) {
+    sh.UW = reinterpret_cast<double2*>(smem);
+    sh.diag = reinterpret_cast<double*>(sh.UW + (size_t)kd * n);
+    sh.dlt = sh.diag + n; sh.rbv = sh.dlt + n; sh.ur = sh.rbv + n; sh.tl = sh.ur + n;
+    sh.site = reinterpret_cast<int*>(sh.tl + 32);
+    sh.newf = reinterpret_cast<signed char*>(sh.site + n);
+    if (regs) { sh.diag2 = reinterpret_cast<double*>(smem + scan_lds_bytes(n, kd, false)); sh.acc_site = reinterpret_cast<int*>(sh.diag2 + n); }
+}
+
 // MAXT: the launch bound.  For n <= 256 the kernel runs one wave per SIMD and may use the whole 512-entry register
-// file; under a 1024-thread bound (128 VGPRs) the prefetch groups spill around every accepted flip (measured:
-// 2000 cycles per flip).
+// file (walk v3); under a 1024-thread bound (128 VGPRs) only the LDS variant fits.
 template <int MAXT>
 __global__ __launch_bounds__(MAXT) void scan_kernel(UpdateDesc d, int l, int acc_slot, int first, int kd) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -160,13 +394,10 @@ __global__ __launch_bounds__(MAXT) void scan_kernel(UpdateDesc d, int l, int acc
     const int n = d.n;
     const int j = threadIdx.x;
     const bool live = j < n;
+    constexpr bool REGS = MAXT <= 256;
 
     ScanShared sh;
-    sh.UW = reinterpret_cast<double2*>(smem);
-    sh.diag = reinterpret_cast<double*>(sh.UW + (size_t)kd * n);
-    sh.dlt = sh.diag + n; sh.rbv = sh.dlt + n; sh.ur = sh.rbv + n; sh.tl = sh.ur + n;
-    sh.site = reinterpret_cast<int*>(sh.tl + 32);
-    sh.newf = reinterpret_cast<signed char*>(sh.site + n);
+    scan_shared_init(sh, smem, n, kd, REGS);
 
     double* __restrict__ G = d.G.at(chain);
     int* state = d.state + (long)chain * d.state_stride;
@@ -212,16 +443,21 @@ __global__ __launch_bounds__(MAXT) void scan_kernel(UpdateDesc d, int l, int acc
 #else
 #define PROF_PASS
 #endif
-    double pcA[SCAN_PF], prA[SCAN_PF], pcB[SCAN_PF], prB[SCAN_PF];
-    int g = pos / SCAN_PF;
-    scan_prefetch(pcA, prA, G, sh, g, n, j, live);
-    scan_prefetch(pcB, prB, G, sh, g + 1, n, j, live);
-    for (;;) {
-        if (!scan_group(pcA, prA, sh, g, n, kd, j, live, pos, k, d, slice_off, chain, fields_g, Up, Wp PROF_PASS)) break;
-        scan_prefetch(pcA, prA, G, sh, g + 2, n, j, live);
-        if (!scan_group(pcB, prB, sh, g + 1, n, kd, j, live, pos, k, d, slice_off, chain, fields_g, Up, Wp PROF_PASS)) break;
-        scan_prefetch(pcB, prB, G, sh, g + 3, n, j, live);
-        g += 2;
+    if constexpr (REGS) {
+        const double* __restrict__ GT = d.GT.at(chain);
+        k = walk_window<false>(sh, pos, live ? sh.diag[j] : 0.0, n, kd, j, live, G, GT, d, slice_off, chain, fields_g, Up, Wp PROF_PASS);
+    } else {
+        double pcA[SCAN_PF], prA[SCAN_PF], pcB[SCAN_PF], prB[SCAN_PF];
+        int g = pos / SCAN_PF;
+        scan_prefetch<false>(pcA, prA, G, sh, g, n, j, live);
+        scan_prefetch<false>(pcB, prB, G, sh, g + 1, n, j, live);
+        for (;;) {
+            if (!scan_group<false>(pcA, prA, sh, g, n, kd, j, live, pos, k, d, slice_off, chain, fields_g, Up, Wp PROF_PASS)) break;
+            scan_prefetch<false>(pcA, prA, G, sh, g + 2, n, j, live);
+            if (!scan_group<false>(pcB, prB, sh, g + 1, n, kd, j, live, pos, k, d, slice_off, chain, fields_g, Up, Wp PROF_PASS)) break;
+            scan_prefetch<false>(pcB, prB, G, sh, g + 3, n, j, live);
+            g += 2;
+        }
     }
     if (j == 0) {
         state[0] = pos;
@@ -236,10 +472,49 @@ __global__ __launch_bounds__(MAXT) void scan_kernel(UpdateDesc d, int l, int acc
     }
 }
 
-// G[a,b] += sum_{m<k} Up[m][a] * Wp[m][b];  one wave per 16x16 tile, 2x2 waves per block.
-// Latency matters more than flops here (N x k x N with k <= 32): the window's pair count k, the G tile and the
-// panel rows are all loaded in ONE round trip (panel rows unconditionally for all KD slots -- stale slots are
-// masked after the fact), instead of k -> panels -> G one after the other.
+// One wave's share of a flush: G[a,b] += sum_{m<k} U_m[a] W_m[b] on its 16x16 sub-tile, and (WITH_GT) the mirrored
+// sub-tile of the transposed copy GT[b,a].  Latency matters more than flops here (N x k x N with k <= 32): the G tile
+// and the panel rows are all loaded in ONE round trip (panel rows unconditionally for all KD slots -- stale slots are
+// masked after the fact).  The second MFMA chain (operands swapped) produces the transposed tile in the layout whose
+// stores are coalesced, instead of scattering the first chain's accumulators.
+template <bool COH, bool WITH_GT>
+__device__ __forceinline__ void flush_tile(double* __restrict__ G, double* __restrict__ GT, const double* __restrict__ Up, const double* __restrict__ Wp,
+                                           int a0, int b0, int n, int k, int kd, int lane) {
+    const int r = lane & 15, kk = lane >> 4;
+    const int a = min(a0 + r, n - 1), b = min(b0 + r, n - 1);          // clamped: loads stay unconditional
+    const bool a_ok = a0 + r < n, b_ok = b0 + r < n;
+    double uv[UPDATE_KD / 4], wv[UPDATE_KD / 4], gv[4], gt[4];
+#pragma unroll
+    for (int s = 0; s < UPDATE_KD / 4; ++s) {
+        const int m = min(4 * s + kk, kd - 1);
+        if (COH) { wv[s] = ld_coh(Wp + m * n + b); uv[s] = ld_coh(Up + m * n + a); }
+        else { wv[s] = Wp[m * n + b]; uv[s] = Up[m * n + a]; }
+    }
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        const int bb = min(b0 + kk + 4 * reg, n - 1), aa = min(a0 + kk + 4 * reg, n - 1);
+        if (COH) { gv[reg] = ld_coh(G + a + (long)n * bb); if (WITH_GT) gt[reg] = ld_coh(GT + b + (long)n * aa); }
+        else { gv[reg] = G[a + (long)n * bb]; if (WITH_GT) gt[reg] = GT[b + (long)n * aa]; }
+    }
+    if (k == 0) return;
+    d4 acc = {0.0, 0.0, 0.0, 0.0}, acc_t = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < UPDATE_KD / 4; ++s) {
+        const bool ok = 4 * s + kk < k;
+        const double wm = (ok && b_ok) ? wv[s] : 0.0, um = (ok && a_ok) ? uv[s] : 0.0;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wm, um, acc, 0, 0, 0);                     // A: rows <-> b, B: cols <-> a
+        if (WITH_GT) acc_t = __builtin_amdgcn_mfma_f64_16x16x4f64(um, wm, acc_t, 0, 0, 0);    // A: rows <-> a, B: cols <-> b
+    }
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        const int bb = b0 + kk + 4 * reg, aa = a0 + kk + 4 * reg;
+        if (a_ok && bb < n) { if (COH) st_coh(G + a + (long)n * bb, gv[reg] + acc[reg]); else G[a + (long)n * bb] = gv[reg] + acc[reg]; }
+        if (WITH_GT && b_ok && aa < n) { if (COH) st_coh(GT + b + (long)n * aa, gt[reg] + acc_t[reg]); else GT[b + (long)n * aa] = gt[reg] + acc_t[reg]; }
+    }
+}
+
+// one block per 32x32 tile, 2x2 waves
+template <bool WITH_GT>
 __global__ __launch_bounds__(256) void flush_kernel(UpdateDesc d, int tiles_per_dim, int kd) {
     const int chain = blockIdx.y;
     const int n = d.n;
@@ -247,41 +522,141 @@ __global__ __launch_bounds__(256) void flush_kernel(UpdateDesc d, int tiles_per_
     const int a0 = (blockIdx.x % tiles_per_dim) * 32 + (wave & 1) * 16;
     const int b0 = (blockIdx.x / tiles_per_dim) * 32 + (wave >> 1) * 16;
     if (a0 >= n || b0 >= n) return;
-    const double* __restrict__ Up = d.Upanel + (long)chain * d.panel_stride;
-    const double* __restrict__ Wp = d.Wpanel + (long)chain * d.panel_stride;
-    double* __restrict__ G = d.G.at(chain);
-    const int r = lane & 15, kk = lane >> 4;
-    const int a = min(a0 + r, n - 1), b = min(b0 + r, n - 1);          // clamped: loads stay unconditional
-    const bool a_ok = a0 + r < n, b_ok = b0 + r < n;
     const int k = d.state[(long)chain * d.state_stride + 1];
-    double uv[UPDATE_KD / 4], wv[UPDATE_KD / 4], gv[4];
-#pragma unroll
-    for (int s = 0; s < UPDATE_KD / 4; ++s) {
-        const int m = min(4 * s + kk, kd - 1);
-        wv[s] = Wp[m * n + b]; uv[s] = Up[m * n + a];
+    flush_tile<false, WITH_GT>(d.G.at(chain), WITH_GT ? d.GT.at(chain) : nullptr, d.Upanel + (long)chain * d.panel_stride, d.Wpanel + (long)chain * d.panel_stride,
+                               a0, b0, n, k, kd, lane);
+}
+
+// ---- persistent slice kernel: the whole local update of one time slice in ONE launch --------------------------------
+// grid = (1 + F, chains): workgroup 0 of a chain runs the serial Metropolis walk (window after window); the other
+// F = (n/32)^2 workgroups each own one 32x32 tile of G (and its mirror in GT) and apply every window's low-rank
+// correction to it.  Replaces ceil(n/KD) x (scan launch + flush launch) per slice: per window the cost of two kernel
+// boundaries, a cold prologue and an empty-launch tail becomes one publish / arrive hand-off.
+//
+// Hand-off (cdna_hip_programming.md Guideline 16; placement-independent, every shared word an agent-scope access):
+//   walk  -> flush : when a window closes the panel rows are written with sc1 stores, every wave drains
+//                    (s_waitcnt vmcnt(0)), the workgroup barriers, one lane stores the granule
+//                    {tag = window number, value = k | final << 31}.  Flush workgroups poll that ONE word.
+//   flush -> walk  : tiles are read and written with sc1 accesses; each flush wave drains, barrier, one lane adds 1 to
+//                    the arrival counter; the walk polls the counter for F * window, then re-reads the diagonal and
+//                    restarts its prefetch with sc1 loads (no L1 copy of G is ever trusted).
+//   The words are zeroed by the LAST workgroup to leave (exit ticket), ready for the next launch; spins are bounded.
+// Needs all 1 + F workgroups of a chain co-resident (the walk's LDS allows one workgroup per CU), so the launcher only
+// takes this path while (1 + F) * chains fits the CU count, and falls back to the multi-kernel path otherwise.
+struct SliceSync { unsigned long long seq; unsigned int arrived; unsigned int exits; unsigned int error; unsigned int pad[11]; };   // 64 B per chain
+constexpr unsigned SLICE_SPIN_LIMIT = 1u << 20;
+
+__global__ __launch_bounds__(256) void slice_kernel(UpdateDesc d, SliceSync* sync_p, int l, int acc_slot, int kd, int tiles_per_dim, int* info) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int chain = blockIdx.y;
+    const int n = d.n;
+    const int F = tiles_per_dim * tiles_per_dim;
+    SliceSync* sy = sync_p + chain;
+    double* __restrict__ G = d.G.at(chain);
+    double* __restrict__ GT = d.GT.at(chain);
+    double* __restrict__ Up = d.Upanel + (long)chain * d.panel_stride;
+    double* __restrict__ Wp = d.Wpanel + (long)chain * d.panel_stride;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+
+    if (blockIdx.x > 0) {
+        // ================= flush role: one 32x32 tile of G, one 16x16 sub-tile per wave =================
+        const int tile = blockIdx.x - 1;
+        const int a0 = (tile % tiles_per_dim) * 32 + (wave & 1) * 16;
+        const int b0 = (tile / tiles_per_dim) * 32 + (wave >> 1) * 16;
+        for (unsigned win = 1;; ++win) {
+            unsigned long long word = 0; unsigned spins = 0; bool give_up = false;
+            for (;;) {
+                word = __hip_atomic_load(&sy->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((unsigned)(word >> 32) == win) break;
+                if (++spins > SLICE_SPIN_LIMIT) { give_up = true; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (give_up) { if (t == 0) { __hip_atomic_store(&sy->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (info) atomicOr(info, 4); } break; }
+            const int k = (int)(word & 0x7fffffffULL);
+            const bool final = (word >> 31) & 1ULL;
+            if (k > 0 && a0 < n && b0 < n) flush_tile<true, true>(G, GT, Up, Wp, a0, b0, n, k, kd, lane);
+            if (final) break;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains before the arrival is signalled
+            __syncthreads();
+            if (t == 0) __hip_atomic_fetch_add(&sy->arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    } else {
+        // ================= walk role =================
+        const int j = t;
+        const bool live = j < n;
+        ScanShared sh;
+        scan_shared_init(sh, smem, n, kd, true);
+        const double* tab_g = reinterpret_cast<const double*>(d.tabs + chain);
+        const long slice_off = (long)l * n;
+        int8_t* fields_g = d.fields + (long)chain * d.f_stride + slice_off;
+        double dg = 0.0;
+        if (live) {
+            const long off = (long)chain * d.rs_stride + slice_off + j;
+            const int i = d.perm[off];
+            const int kp = d.kprop[off];
+            const int old_f = fields_g[i];
+            sh.site[j] = i; sh.newf[j] = (signed char)c_proposal[old_f][kp];
+            sh.rbv[j] = tab_g[old_f * 3 + kp]; sh.dlt[j] = tab_g[12 + old_f * 3 + kp]; sh.ur[j] = d.u[off];
+            dg = G[j + (long)n * j];                                  // first window: G was written by the previous kernel
+            sh.diag[j] = dg;
+        }
+        if (j < 32) sh.tl[j] = tab_g[j];
+        __syncthreads();
+        int pos = 0, total_acc = 0;
+        bool broken = false;
+#ifdef DQ_SCAN_STAMPS
+        ScanProf prof; unsigned long long tk0, t_hand = 0; STAMP(tk0)
+#endif
+        for (unsigned win = 1;; ++win) {
+            const int k = walk_window<true>(sh, pos, dg, n, kd, j, live, G, GT, d, slice_off, chain, fields_g, Up, Wp PROF_PASS);
+            total_acc += k;
+            const bool final = pos >= n;
+#ifdef DQ_SCAN_STAMPS
+            unsigned long long th0; STAMP(th0)
+#endif
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // panel stores of every wave have left the CU
+            __syncthreads();
+            if (t == 0) __hip_atomic_store(&sy->seq, ((unsigned long long)win << 32) | ((unsigned long long)final << 31) | (unsigned long long)k,
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (final) break;
+            // wait until every tile has absorbed this window, then refresh the diagonal from the flushed G
+            if (wave == 0) {
+                unsigned spins = 0;
+                while (__hip_atomic_load(&sy->arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)F * win) {
+                    if (++spins > SLICE_SPIN_LIMIT) { broken = true; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (broken && lane == 0) { __hip_atomic_store(&sy->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (info) atomicOr(info, 4); }
+            }
+            __syncthreads();
+            if (live) { dg = ld_coh(G + j + (long)n * j); sh.diag[j] = dg; }     // G changed: diagonal and prefetch restart from memory
+            __syncthreads();
+#ifdef DQ_SCAN_STAMPS
+            { unsigned long long th1; STAMP(th1) t_hand += th1 - th0; }
+#endif
+        }
+        if (j == 0) d.acc_out[(long)chain * d.acc_stride + acc_slot] = total_acc;
+#ifdef DQ_SCAN_STAMPS
+        if (j == 0) { unsigned long long tk1; STAMP(tk1)
+            printf("slice l=%d: total %llu cyc | hand-offs %llu | %d acc: decide+fetch %llu pairs %llu tail %llu\n", l, tk1 - tk0, t_hand, prof.n_acc,
+                   prof.t_wait, prof.t_kloop, prof.t_tail); }
+#endif
     }
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) { const int bb = min(b0 + kk + 4 * reg, n - 1); gv[reg] = G[a + (long)n * bb]; }
-    if (k == 0) return;
-    d4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int s = 0; s < UPDATE_KD / 4; ++s) {
-        const int m = 4 * s + kk;
-        const bool ok = m < k;
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64((ok && b_ok) ? wv[s] : 0.0, (ok && a_ok) ? uv[s] : 0.0, acc, 0, 0, 0);   // A: rows <-> b, B: cols <-> a
-    }
-    if (a_ok) {
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            const int bb = b0 + kk + 4 * reg;
-            if (bb < n) G[a + (long)n * bb] = gv[reg] + acc[reg];
+    // exit ticket: the last workgroup of the chain to leave re-arms the sync words for the next launch
+    __syncthreads();
+    if (t == 0) {
+        const unsigned ticket = __hip_atomic_fetch_add(&sy->exits, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (ticket == (unsigned)F) {
+            __hip_atomic_store(&sy->seq, 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&sy->arrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&sy->exits, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
 
 static int pick_kd(int n) {
-    // LDS budget: 16*kd*n + n*(4*8+4+1) + tables <= ~150 KiB
-    const long budget = 150 * 1024 - (long)n * 40 - 512;
+    // LDS budget: 16*kd*n + n*(5*8+4+1) + tables <= ~150 KiB
+    const long budget = 150 * 1024 - (long)n * 48 - 1024;
     long kd = budget / (16L * n);
     if (kd > UPDATE_KD) kd = UPDATE_KD;
     if (kd < 1) kd = 1;
@@ -293,19 +668,37 @@ int launch_update_slice(const UpdateDesc& d, int l, int acc_slot, int n_chains, 
     if (n > 1024) { set_error("local update kernel supports n_sites <= 1024"); return -1; }
     const int kd = pick_kd(n);
     const int threads = ((n + 63) / 64) * 64;
-    const size_t lds = (size_t)16 * kd * n + (size_t)n * 32 + 256 + (size_t)n * 4 + (size_t)n + 64;
+    const bool regs = threads <= 256;                               // walk v3 (register-resident pending pairs, needs GT)
+    const size_t lds = scan_lds_bytes(n, kd, regs);
     static bool attr_set = false;
     if (!attr_set) {
         DQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(scan_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         DQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(scan_kernel<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        DQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(slice_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    const int windows = (n + kd - 1) / kd;
     const int tiles = (n + 31) / 32;
+    if (regs) {
+        if (!d.GT.p) { set_error("local update: transposed workspace missing"); return -1; }
+        if (int rc = launch_transpose_scale(CMat(d.G.p, d.G.stride), d.GT, CVec(), n, n_chains, s)) return rc;      // GT = G^T, kept in step by the flushes
+    }
+    static const bool multi_kernel = getenv("DQMC_SLICE_MULTIKERNEL") != nullptr;      // A/B switch
+    // persistent single-launch path: needs every workgroup of a chain resident at once, one per CU (the walk's LDS)
+    if (!multi_kernel && regs && d.slice_sync && (long)(1 + tiles * tiles) * n_chains <= 224) {
+        hipLaunchKernelGGL(slice_kernel, dim3(1 + tiles * tiles, n_chains), dim3(256), lds, s, d, reinterpret_cast<SliceSync*>(d.slice_sync), l, acc_slot, kd,
+                           tiles, d.info);
+        DQ_HIP(hipGetLastError());
+        return 0;
+    }
+    const int windows = (n + kd - 1) / kd;
     for (int w = 0; w < windows; ++w) {
-        if (threads <= 256) hipLaunchKernelGGL(scan_kernel<256>, dim3(1, n_chains), dim3(threads), lds, s, d, l, acc_slot, w == 0 ? 1 : 0, kd);
-        else hipLaunchKernelGGL(scan_kernel<1024>, dim3(1, n_chains), dim3(threads), lds, s, d, l, acc_slot, w == 0 ? 1 : 0, kd);
-        hipLaunchKernelGGL(flush_kernel, dim3(tiles * tiles, n_chains), dim3(256), 0, s, d, tiles, kd);
+        if (regs) {
+            hipLaunchKernelGGL(scan_kernel<256>, dim3(1, n_chains), dim3(threads), lds, s, d, l, acc_slot, w == 0 ? 1 : 0, kd);
+            hipLaunchKernelGGL(flush_kernel<true>, dim3(tiles * tiles, n_chains), dim3(256), 0, s, d, tiles, kd);
+        } else {
+            hipLaunchKernelGGL(scan_kernel<1024>, dim3(1, n_chains), dim3(threads), lds, s, d, l, acc_slot, w == 0 ? 1 : 0, kd);
+            hipLaunchKernelGGL(flush_kernel<false>, dim3(tiles * tiles, n_chains), dim3(256), 0, s, d, tiles, kd);
+        }
     }
     DQ_HIP(hipGetLastError());
     return 0;
