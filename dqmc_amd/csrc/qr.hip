@@ -253,6 +253,7 @@ __global__ void assemble_r_kernel(CMat Am, const int* jpvt_p, long jpvt_stride, 
 
 int launch_qrcp_onchip(Mat A, QrWork w, int n, int n_chains, hipStream_t s);   // qr_onchip.hip
 int launch_qrcp_coop(Mat A, QrWork w, int n, int n_chains, hipStream_t s);     // qr_coop.hip
+int launch_qrcp_colown(Mat A, QrWork w, int n, int n_chains, hipStream_t s);   // qr_colown.hip
 
 // NRSEL = 0: on-chip QRCP (n <= 256); otherwise the streaming kernel with NRSEL rows per lane
 template <int NRSEL>
@@ -263,8 +264,10 @@ static int launch_to_ldr_nr(Mat A, Mat L, Vec d, Mat R, QrWork w, int n, int n_c
         // (opt-in: measured 1.26 ms vs 1.22 ms for the single-workgroup kernel at n = 256 -- a cross-CU round trip costs
         // ~1.5 us on this chip and a step needs three of them -- so the default stays the kernel with no cross-workgroup protocol)
         static const bool use_coop = getenv("DQMC_QR_COOP") != nullptr;
+        static const bool use_blockcyclic = getenv("DQMC_QR_BLOCKCYCLIC") != nullptr;     // A/B switch: the 2-D block-cyclic single-workgroup kernel
         if (n > 128 && w.sync && use_coop && 8 * n_chains <= 2048) DQ_TRY_RC(launch_qrcp_coop(A, w, n, n_chains, s));
-        else DQ_TRY_RC(launch_qrcp_onchip(A, w, n, n_chains, s));
+        else if (use_blockcyclic) DQ_TRY_RC(launch_qrcp_onchip(A, w, n, n_chains, s));
+        else DQ_TRY_RC(launch_qrcp_colown(A, w, n, n_chains, s));
         hipLaunchKernelGGL((formq_kernel<4 * NR>), dim3((n + 15) / 16, n_chains), dim3(256), 0, s, CMat(A), (const double*)w.tau, w.tau_stride,
                            (const int*)w.jpvt, w.jpvt_stride, L, n);
         hipLaunchKernelGGL(assemble_r_kernel, dim3(n, n_chains), dim3(128), 0, s, CMat(A), (const int*)w.jpvt, w.jpvt_stride, d, R, n);

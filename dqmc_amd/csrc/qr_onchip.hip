@@ -72,6 +72,15 @@ struct OcShared {
 #endif
 
 // All steps i in row block JB (i = 16*JB .. min(16*JB+15, n-1)).
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a release fence = s_waitcnt vmcnt(0): with the
+// reflector / R0 stores to HBM issued every step, each of the three barriers of a step waited for a store round trip.
+// Those stores are consumed by other kernels only (formq, assemble_r), never by this workgroup through memory.
+__device__ __forceinline__ void oc_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 template <int JB>
 __device__ __forceinline__ void qr_block(double (&a)[OC_KR][16], int& livem, unsigned& wlive, const OcShared& sh, double* __restrict__ A,
                                          double* tau, int* jpvt, int n, int t, int lane, int wave, int rg, int cl, int cbase
@@ -135,7 +144,7 @@ __device__ __forceinline__ void qr_block(double (&a)[OC_KR][16], int& livem, uns
             }
         }
         QSTAMP(q1)
-        __syncthreads();
+        oc_barrier();
         QSTAMP(q2)
         // ---- [B] Householder vector (dlarfg) ----
         const double tau_i = sh.scal[0], beta = sh.scal[1], scale = sh.scal[2];
@@ -149,7 +158,7 @@ __device__ __forceinline__ void qr_block(double (&a)[OC_KR][16], int& livem, uns
         if (t == 0) { tau[i] = tau_i; jpvt[i] = p; sh.pposl[p] = i; }
         if (up == cbase) livem &= ~(1 << kcp);
         if ((up >> 2) == wave) wlive &= ~(1u << qp);
-        __syncthreads();
+        oc_barrier();
         QSTAMP(q3)
         // ---- [C] apply H to my live columns: two passes over the live row blocks, two blocks per trip ----
         {
@@ -258,7 +267,7 @@ __device__ __forceinline__ void qr_block(double (&a)[OC_KR][16], int& livem, uns
                 }
             }
         }
-        __syncthreads();
+        oc_barrier();
     }
 }
 
