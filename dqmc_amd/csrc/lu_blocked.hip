@@ -28,14 +28,21 @@ __device__ __forceinline__ unsigned long long piv_key(double a, int r) {
     // |a| ordered as an unsigned integer; low 10 bits carry 1023 - row so equal magnitudes pick the lowest row (idamax)
     return ((unsigned long long)__double_as_longlong(fabs(a)) & ~0x3FFULL) | (unsigned long long)(1023 - r);
 }
+// workgroup barrier that orders LDS traffic only (no vmcnt(0): see update.hip)
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
 }  // namespace
 
 // rowpos: [chains][n] ints, -1 = live row, else the elimination step that made it a pivot row.
 __global__ __launch_bounds__(1024) void lu_panel_kernel(Mat Am, int* perm_p, long perm_stride, int* rowpos_p, long rowpos_stride,
                                                         double* logabsdet, int accumulate, int* info, int n, int k0) {
-    __shared__ double prow[LU_NB];
+    __shared__ __attribute__((aligned(16))) double prow[LU_NB];
     __shared__ double pivs[LU_NB];
     __shared__ unsigned long long keys[16];
+    __shared__ int perml[LU_NB];
     const int chain = blockIdx.y;
     double* __restrict__ A = Am.at(chain);
     int* perm = perm_p + (long)chain * perm_stride;
@@ -56,18 +63,19 @@ __global__ __launch_bounds__(1024) void lu_panel_kernel(Mat Am, int* perm_p, lon
             unsigned long long key = live ? piv_key(a[j], t) | (1ULL << 63) : 0ULL;
             key = wave_max_u64(key);
             if (lane == 0) keys[wave] = key;
-            __syncthreads();
+            lds_barrier();
             unsigned long long best = keys[0];
             for (int q = 1; q < nwaves; ++q) { const unsigned long long o = keys[q]; best = o > best ? o : best; }
             const int p = 1023 - (int)(best & 0x3FFULL);
             if (t == p) {                                // publish the part of the pivot row still needed
+                // an LDS store costs ~14-28 clk whatever the number of active lanes: publish in 16-byte pairs (even start)
 #pragma unroll
-                for (int c = j; c < LU_NB; ++c) prow[c] = a[c];
+                for (int c = (j & ~1); c < LU_NB; c += 2) *reinterpret_cast<double2*>(prow + c) = make_double2(a[c], a[c + 1]);
                 pivs[j] = a[j];
                 live = false; my_pos = k0 + j;
-                perm[k0 + j] = p;
+                perml[j] = p;                            // to memory after the loop: a global store here put a vmcnt(0) wait into the next barrier
             }
-            __syncthreads();
+            lds_barrier();
             const double rpiv = 1.0 / prow[j];           // dgetf2 scales by the reciprocal pivot as well
             if (live) {
                 const double l = a[j] * rpiv;
@@ -82,6 +90,7 @@ __global__ __launch_bounds__(1024) void lu_panel_kernel(Mat Am, int* perm_p, lon
         for (int c = 0; c < LU_NB; ++c) if (c < nbw) A[t + (long)n * (k0 + c)] = a[c];
         if (k0 == 0) rowpos[t] = my_pos; else if (my_pos >= 0) rowpos[t] = my_pos;
     }
+    if (t < nbw) perm[k0 + t] = perml[t];
     __syncthreads();
     if (wave == 0) {                                     // log|det| contribution and singularity check, off the critical path
         const double pv = lane < nbw ? fabs(pivs[lane]) : 1.0;
