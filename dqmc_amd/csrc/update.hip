@@ -91,7 +91,7 @@ __device__ __forceinline__ void scan_prefetch(double (&pc)[SCAN_PF], double (&pr
 // processes the proposals of group g from position `pos` on; returns false when the window is full or the walk is over
 #ifdef DQ_SCAN_STAMPS
 #define STAMP(v) { unsigned long long _t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t) :: "memory"); v = _t; }
-struct ScanProf { unsigned long long t_rej = 0, t_kloop = 0, t_tail = 0, t_wait = 0; int n_rej = 0, n_acc = 0; };
+struct ScanProf { unsigned long long t_rej = 0, t_kloop = 0, t_tail = 0, t_wait = 0, t_first = 0, t_dump = 0, t_noacc = 0; int n_rej = 0, n_acc = 0, n_noacc = 0; };
 #define PROF_ARG , ScanProf& prof
 #else
 #define PROF_ARG
@@ -227,6 +227,7 @@ __device__ __forceinline__ void walk_load_group(double (&pc)[8], double (&pr)[8]
     }
 }
 __device__ __forceinline__ d16v vec_set(d16v v, int q, double x) { v[q] = x; return v; }
+__device__ __forceinline__ double vec_get16(d16v v, int q) { return v[q]; }
 
 #define DQ_PICK8(PC, PR)                                                                                            \
     switch (first) {                                                                                                \
@@ -271,6 +272,9 @@ __device__ __forceinline__ int walk_window(const ScanShared& sh, int& pos, doubl
     int par = 0, k = 0;
     int g = pos >> 3;
     bool done = false;
+#ifdef DQ_SCAN_STAMPS
+    unsigned long long tw0; STAMP(tw0) bool first_acc = true;
+#endif
     // sets of groups g and g + 1 (the group macro below requests g + 2 when it starts on g)
     switch (g % 3) {
         case 0: walk_load_group<COH>(pc0, pr0, G, GT, sh, g, n, j, live); walk_load_group<COH>(pc1, pr1, G, GT, sh, g + 1, n, j, live); break;
@@ -286,25 +290,26 @@ __device__ __forceinline__ int walk_window(const ScanShared& sh, int& pos, doubl
     {                                                                                                                                    \
         walk_load_group<COH>(PCT, PRT, G, GT, sh, g + 2, n, j, live);                                                                    \
         const int gbase = g * 8;                                                                                                         \
+        /* what lane q needs to decide proposal gbase + q is read once per group; only the diagonal changes between passes */           \
+        const int p_l = gbase + q8, pc_l = min(p_l, n - 1);                                                                              \
+        const int i_l = sh.site[pc_l];                                                                                                   \
+        const double dl_l = sh.dlt[pc_l], rb_l = sh.rbv[pc_l], ur_l = sh.ur[pc_l];                                                       \
         for (;;) {                                                                                                                       \
             DQ_ST(unsigned long long t0, t1, t2, t3; STAMP(t0))                                                                          \
             /* decisions for the (remaining) proposals of the group under the current diagonal: lane q <-> proposal gbase + q */         \
-            const int p_l = gbase + q8, pc_l = min(p_l, n - 1);                                                                          \
-            const int i_l = sh.site[pc_l];                                                                                               \
-            const double dl_l = sh.dlt[pc_l];                                                                                            \
             const double* dcur = par ? sh.diag2 : sh.diag;                                                                               \
             const double r_l = 1.0 + (1.0 - dcur[i_l]) * dl_l;                 /* det ratio per flavour (source/model.cpp:95) */          \
-            const double R_l = sh.rbv[pc_l] * (r_l * r_l);                      /* :121 */                                               \
+            const double R_l = rb_l * (r_l * r_l);                              /* :121 */                                               \
+            const double pref_l = dl_l / r_l;                                   /* source/model.cpp:132, for every candidate: the division overlaps the decision */ \
             /* bernoulli(min(1,|R|)): u < p (source/update.cpp:24, include/utility.h:34-37) */                                           \
-            const bool acc_l = p_l >= pos && p_l < n && sh.ur[pc_l] < fmin(1.0, fabs(R_l));                                              \
+            const bool acc_l = p_l >= pos && p_l < n && ur_l < fmin(1.0, fabs(R_l));                                                     \
             const unsigned bal = (unsigned)__ballot(acc_l) & 0xffu;                                                                      \
-            if (bal == 0u) { pos = min(gbase + 8, n); break; }                  /* the rest of the group is rejected */                  \
+            if (bal == 0u) { pos = min(gbase + 8, n); DQ_ST(STAMP(t1) prof.t_noacc += t1 - t0; prof.n_noacc++;) break; }   /* the rest of the group is rejected */ \
             const int first = __ffs((int)bal) - 1;                                                                                       \
             const int p = gbase + first;                                                                                                 \
             pos = p + 1;                                                                                                                 \
             const int i = __builtin_amdgcn_readlane(i_l, first);                                                                         \
-            const double delta = readlane_f64(dl_l, first), r = readlane_f64(r_l, first);                                                \
-            const double pref = delta / r;                                      /* source/model.cpp:132 */                               \
+            const double pref = readlane_f64(pref_l, first);                                                                             \
             /* pivot pairs: lane r16 of every row holds {U_m[i], W_m[i]} for m = r16 (pa) and m = 16 + r16 (pb) */                        \
             const int kc = max(k - 1, 0);                                                                                                \
             double2 pa = sh.UW[min(r16, kc) * n + i], pb = sh.UW[min(16 + r16, kc) * n + i];                                             \
@@ -312,18 +317,14 @@ __device__ __forceinline__ int walk_window(const ScanShared& sh, int& pos, doubl
             if (16 + r16 >= k) { pb.x = 0.0; pb.y = 0.0; }                                                                               \
             double uj, wj;                                                                                                               \
             DQ_PICK8(PCS, PRS)                                                                                                           \
-            DQ_ST(STAMP(t1))                                                                                                             \
+            DQ_ST(STAMP(t1) if (first_acc) { first_acc = false; asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); unsigned long long tf; STAMP(tf) prof.t_first += tf - tw0; })  \
             /* G_eff[:, i], G_eff[i, :]: 2k FMAs per lane, pivot operand broadcast by DPP */                                             \
             double u1 = 0.0, w1 = 0.0;                                                                                                   \
-            if (k > 0) {                                                                                                                 \
-                DQ_FMAC4(0, 1, 2, 3, uj, wj, u1, w1, pa.x, pa.y, ou0, ow0, 0);                                                           \
-                if (k > 4) DQ_FMAC4(4, 5, 6, 7, uj, wj, u1, w1, pa.x, pa.y, ou0, ow0, 4);                                                \
-                if (k > 8) DQ_FMAC4(8, 9, 10, 11, uj, wj, u1, w1, pa.x, pa.y, ou0, ow0, 8);                                              \
-                if (k > 12) DQ_FMAC4(12, 13, 14, 15, uj, wj, u1, w1, pa.x, pa.y, ou0, ow0, 12);                                          \
-                if (k > 16) DQ_FMAC4(0, 1, 2, 3, uj, wj, u1, w1, pb.x, pb.y, ou1, ow1, 0);                                               \
-                if (k > 20) DQ_FMAC4(4, 5, 6, 7, uj, wj, u1, w1, pb.x, pb.y, ou1, ow1, 4);                                               \
-                if (k > 24) DQ_FMAC4(8, 9, 10, 11, uj, wj, u1, w1, pb.x, pb.y, ou1, ow1, 8);                                             \
-                if (k > 28) DQ_FMAC4(12, 13, 14, 15, uj, wj, u1, w1, pb.x, pb.y, ou1, ow1, 12);                                          \
+            if (k > 0) {                                        /* eight pairs per scalar branch (slots k.. of the last octet hold zeros in pa / pb) */ \
+                DQ_FMAC4(0, 1, 2, 3, uj, wj, u1, w1, pa.x, pa.y, ou0, ow0, 0); DQ_FMAC4(4, 5, 6, 7, uj, wj, u1, w1, pa.x, pa.y, ou0, ow0, 4);     \
+                if (k > 8) { DQ_FMAC4(8, 9, 10, 11, uj, wj, u1, w1, pa.x, pa.y, ou0, ow0, 8); DQ_FMAC4(12, 13, 14, 15, uj, wj, u1, w1, pa.x, pa.y, ou0, ow0, 12); }   \
+                if (k > 16) { DQ_FMAC4(0, 1, 2, 3, uj, wj, u1, w1, pb.x, pb.y, ou1, ow1, 0); DQ_FMAC4(4, 5, 6, 7, uj, wj, u1, w1, pb.x, pb.y, ou1, ow1, 4); }         \
+                if (k > 24) { DQ_FMAC4(8, 9, 10, 11, uj, wj, u1, w1, pb.x, pb.y, ou1, ow1, 8); DQ_FMAC4(12, 13, 14, 15, uj, wj, u1, w1, pb.x, pb.y, ou1, ow1, 12); } \
             }                                                                                                                            \
             uj += u1; wj += w1;                                                                                                          \
             if (j == i) wj -= 1.0;                                              /* V(i) -= 1 (source/model.cpp:135) */                   \
@@ -336,7 +337,11 @@ __device__ __forceinline__ int walk_window(const ScanShared& sh, int& pos, doubl
             }                                                                                                                            \
             if (j == 0) sh.acc_site[k] = p;                                     /* fields are written at window end */                   \
             const int ks = k & 15;                                                                                                       \
-            if (k < 16) { ou0 = vec_set(ou0, ks, pu); ow0 = vec_set(ow0, ks, wj); } else { ou1 = vec_set(ou1, ks, pu); ow1 = vec_set(ow1, ks, wj); } \
+            { /* branch-free slot write: an if / else around the two halves makes every vector a phi and the allocator copies    */       \
+              /* 32-register tuples (VGPR <-> AGPR) on the loop back-edge -- ~100 moves per accepted flip                         */       \
+                const bool lo = k < 16;                                                                                                  \
+                ou0 = vec_set(ou0, ks, lo ? pu : vec_get16(ou0, ks)); ow0 = vec_set(ow0, ks, lo ? wj : vec_get16(ow0, ks));              \
+                ou1 = vec_set(ou1, ks, lo ? vec_get16(ou1, ks) : pu); ow1 = vec_set(ow1, ks, lo ? vec_get16(ow1, ks) : wj); }            \
             ++k; par ^= 1;                                                                                                               \
             lds_barrier();                                                                                                               \
             DQ_ST(STAMP(t3) prof.t_wait += t1 - t0; prof.t_kloop += t2 - t1; prof.t_tail += t3 - t2; prof.n_acc++;)                      \
@@ -354,6 +359,9 @@ __device__ __forceinline__ int walk_window(const ScanShared& sh, int& pos, doubl
     }
 #undef DQ_GROUP
 #undef DQ_ST
+#ifdef DQ_SCAN_STAMPS
+    unsigned long long td0; STAMP(td0)
+#endif
     // ---- window end: the flush's operands and the accepted field changes leave the workgroup (coalesced, from registers) ----
     if (live) {
 #define DQ_DUMP(OU, OW, M, BASE)                                                                       \
@@ -372,6 +380,9 @@ __device__ __forceinline__ int walk_window(const ScanShared& sh, int& pos, doubl
         d.expv[(long)chain * d.v_stride + slice_off + i] = sh.tl[24 + new_f];
         d.invexpv[(long)chain * d.v_stride + slice_off + i] = sh.tl[28 + new_f];
     }
+#ifdef DQ_SCAN_STAMPS
+    { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); unsigned long long td1; STAMP(td1) prof.t_dump += td1 - td0; }
+#endif
     return k;
 }
 static_assert(UPDATE_KD == 32, "walk v3 keeps 2 x 16 pending pairs per lane in registers");
@@ -522,7 +533,10 @@ __global__ __launch_bounds__(256) void flush_kernel(UpdateDesc d, int tiles_per_
     const int a0 = (blockIdx.x % tiles_per_dim) * 32 + (wave & 1) * 16;
     const int b0 = (blockIdx.x / tiles_per_dim) * 32 + (wave >> 1) * 16;
     if (a0 >= n || b0 >= n) return;
-    const int k = d.state[(long)chain * d.state_stride + 1];
+    // the walk of a slice usually ends after 4 of the 8 launched windows: an empty window must not touch G at all
+    // (batched engines are bandwidth-bound here: 40 % of the flush traffic was for windows with nothing to apply)
+    const int k = __builtin_amdgcn_readfirstlane(d.state[(long)chain * d.state_stride + 1]);
+    if (k == 0) return;
     flush_tile<false, WITH_GT>(d.G.at(chain), WITH_GT ? d.GT.at(chain) : nullptr, d.Upanel + (long)chain * d.panel_stride, d.Wpanel + (long)chain * d.panel_stride,
                                a0, b0, n, k, kd, lane);
 }
@@ -638,8 +652,8 @@ __global__ __launch_bounds__(256) void slice_kernel(UpdateDesc d, SliceSync* syn
         if (j == 0) d.acc_out[(long)chain * d.acc_stride + acc_slot] = total_acc;
 #ifdef DQ_SCAN_STAMPS
         if (j == 0) { unsigned long long tk1; STAMP(tk1)
-            printf("slice l=%d: total %llu cyc | hand-offs %llu | %d acc: decide+fetch %llu pairs %llu tail %llu\n", l, tk1 - tk0, t_hand, prof.n_acc,
-                   prof.t_wait, prof.t_kloop, prof.t_tail); }
+            printf("slice l=%d: total %llu cyc | hand-offs %llu | %d acc: decide+fetch %llu pairs %llu tail %llu | window start->first flip %llu | %d empty passes %llu | dump+drain %llu\n",
+                   l, tk1 - tk0, t_hand, prof.n_acc, prof.t_wait, prof.t_kloop, prof.t_tail, prof.t_first, prof.n_noacc, prof.t_noacc, prof.t_dump); }
 #endif
     }
     // exit ticket: the last workgroup of the chain to leave re-arms the sync words for the next launch
