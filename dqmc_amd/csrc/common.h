@@ -53,6 +53,7 @@ using CVec = CMat;
 struct GemmDesc {
     CMat A, B;
     Mat C;
+    Mat CT{nullptr, 0};   // optional: also receives C^T (fused in the split-K epilogue, a transpose launch otherwise)
     CVec rs, ks, cs;
     int n = 0;
     int transA = 0;
@@ -130,7 +131,8 @@ struct UpdateDesc {
     double* Upanel; double* Wpanel; long panel_stride;   // [chain][KD][n]
     int* state; long state_stride;            // per chain: [0]=pos, [1]=k (accepts in current window), [2]=accepted in slice
     double* prep; long prep_stride;           // per chain 4*n doubles: the slice's G-independent proposal data
-    Mat GT{nullptr, 0};                       // transposed copy of G the n <= 256 walk reads rows from (workspace; rebuilt at every slice)
+    Mat GT{nullptr, 0};                       // transposed copy of G the n <= 256 walk reads rows from; kept in step by the flushes
+    int gt_valid = 0;                         // GT already equals G^T (written by the GEMM that produced G): skip the transpose launch
     void* slice_sync = nullptr;               // per chain 64 zeroed bytes: hand-off words of the persistent slice kernel (null -> multi-kernel path)
     int* info = nullptr;                      // |= 4 when a hand-off of the persistent slice kernel timed out
     int* acc_out; long acc_stride;            // per chain per slice accepted counts [chain][2*nt] (+ offset chosen by caller)

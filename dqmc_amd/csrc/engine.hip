@@ -83,8 +83,8 @@ struct Ctx {
         if (stream) (void)hipStreamDestroy(stream);
     }
 
-    int gemm(CMat A, CMat B, Mat Cm, CVec rs = CVec(), CVec ks = CVec(), CVec cs = CVec(), int transA = 0, int accumulate = 0) {
-        GemmDesc g; g.A = A; g.B = B; g.C = Cm; g.rs = rs; g.ks = ks; g.cs = cs; g.n = n; g.transA = transA; g.accumulate = accumulate;
+    int gemm(CMat A, CMat B, Mat Cm, CVec rs = CVec(), CVec ks = CVec(), CVec cs = CVec(), int transA = 0, int accumulate = 0, Mat CT = Mat{nullptr, 0}) {
+        GemmDesc g; g.A = A; g.B = B; g.C = Cm; g.CT = CT; g.rs = rs; g.ks = ks; g.cs = cs; g.n = n; g.transA = transA; g.accumulate = accumulate;
         return launch_gemm(g, C, stream);
     }
     // stablelinalg::to_LDR (source/stablelinalg.cpp:35-55); A is destroyed
@@ -170,6 +170,7 @@ struct Engine {
     int8_t* fields = nullptr;                                    // [C][nt][n]
     double* expv = nullptr; double* invexpv = nullptr;           // [C][nt][n]
     UpdateTables* tabs = nullptr; double* tab8 = nullptr;        // [C], [C][8]
+    bool gt_valid = false;                                       // GT == G^T right now (set by the wraps, cleared by everything else that writes G)
     double* G = nullptr; double* Gtmp = nullptr; double* GT = nullptr;   // [C][nn]; GT: transposed copy for the local-update walk
     double* bb0 = nullptr; double* bb1 = nullptr;                // Bbar ping-pong
     double* stackL = nullptr; double* stackD = nullptr; double* stackR = nullptr;
@@ -291,22 +292,25 @@ struct Engine {
             else { DQ_TRY(ctx.to_ldr(bb, tmp)); DQ_TRY(ctx.ldr_mul_ldr(stk(i + 1), tmp, stk(i))); }
         }
         stack_valid = true;
+        gt_valid = false;
         return ctx.inv_I_plus_ldr(stk(0), mG(), logdet);
     }
     // DQMC::propagate_GF_forward (source/dqmc.cpp:113-132): G = B_l G B_l^-1
     int wrap_forward(int l) {
         DQ_TRY(ctx.gemm(CMat(expK, nn), mG(), ctx.T(0)));
-        return ctx.gemm(ctx.T(0), CMat(invexpK, nn), mG(), ev(l), CVec(), iev(l));
+        gt_valid = n <= 256;                                          // the GEMM that writes G writes GT as well
+        return ctx.gemm(ctx.T(0), CMat(invexpK, nn), mG(), ev(l), CVec(), iev(l), 0, 0, n <= 256 ? Mat{GT, nn} : Mat{nullptr, 0});
     }
     // DQMC::propagate_GF_backward (source/dqmc.cpp:169-187): G = B_l^-1 G B_l
     int wrap_backward(int l) {
         DQ_TRY(ctx.gemm(CMat(invexpK, nn), mG(), ctx.T(0), CVec(), iev(l)));
-        return ctx.gemm(ctx.T(0), CMat(expK, nn), mG(), CVec(), ev(l));
+        gt_valid = n <= 256;
+        return ctx.gemm(ctx.T(0), CMat(expK, nn), mG(), CVec(), ev(l), CVec(), 0, 0, n <= 256 ? Mat{GT, nn} : Mat{nullptr, 0});
     }
     UpdateDesc udesc() const {
         UpdateDesc d; d.G = mG(); d.fields = fields; d.f_stride = (long)nt * n; d.expv = expv; d.invexpv = invexpv; d.v_stride = (long)nt * n;
         d.tabs = tabs; d.perm = rs_perm; d.kprop = rs_k; d.u = rs_u; d.rs_stride = (long)nt * n; d.Upanel = Upanel; d.Wpanel = Wpanel;
-        d.panel_stride = (long)UPDATE_KD * n; d.state = state; d.state_stride = 4; d.prep = prep; d.prep_stride = 4L * n; d.slice_sync = slice_sync; d.GT = Mat{GT, nn}; d.info = ctx.info(); d.acc_out = acc; d.acc_stride = nt; d.n = n; d.nt = nt;
+        d.panel_stride = (long)UPDATE_KD * n; d.state = state; d.state_stride = 4; d.prep = prep; d.prep_stride = 4L * n; d.slice_sync = slice_sync; d.GT = Mat{GT, nn}; d.gt_valid = gt_valid ? 1 : 0; d.info = ctx.info(); d.acc_out = acc; d.acc_stride = nt; d.n = n; d.nt = nt;
         return d;
     }
     int local_update(int l) {
@@ -346,6 +350,7 @@ struct Engine {
                 Mat bb; DQ_TRY(Bbar(is, &bb));
                 if (is == 0) DQ_TRY(ctx.to_ldr(bb, stk(0)));                                  // update_stack_forward :134-146
                 else DQ_TRY(ctx.mat_mul_ldr(bb, stk(is - 1), stk(is)));
+                gt_valid = false;                                                            // G is replaced below
                 if (l == nt - 1) DQ_TRY(ctx.inv_I_plus_ldr(stk(is), mG(), logdet));           // stabilize_GF_forward :148-161
                 else DQ_TRY(ctx.inv_I_plus_ldr_mul_ldr(stk(is), stk(is + 1), mG()));
                 DQ_TRY(launch_max_abs_diff(CMat(Gtmp, nn), mG(), err + n_err, n_stack, n, C, s));   // check_error :317-329
@@ -366,6 +371,7 @@ struct Engine {
                 Mat bb; DQ_TRY(Bbar(is, &bb));
                 if (is == n_stack - 1) DQ_TRY(ctx.to_ldr(bb, stk(is)));                       // update_stack_backward :189-201
                 else DQ_TRY(ctx.ldr_mul_mat(stk(is + 1), bb, stk(is)));
+                gt_valid = false;
                 if (l == 0) DQ_TRY(ctx.inv_I_plus_ldr(stk(is), mG(), logdet));                // stabilize_GF_backward :203-215
                 else DQ_TRY(ctx.inv_I_plus_ldr_mul_ldr(stk(is - 1), stk(is), mG()));
                 DQ_TRY(launch_max_abs_diff(CMat(Gtmp, nn), mG(), err + n_err, n_stack, n, C, s));
@@ -574,7 +580,7 @@ int dqmc_get_G(dqmc_engine* h, double* G) {
 }
 int dqmc_set_G(dqmc_engine* h, const double* G) {
     CHECK_E(h); Engine& e = h->e; DQ_HIP(hipSetDevice(e.device)); DQ_HIP(hipStreamSynchronize(e.s));
-    DQ_HIP(hipMemcpy(e.G, G, sizeof(double) * e.C * e.nn, hipMemcpyHostToDevice)); return 0;
+    DQ_HIP(hipMemcpy(e.G, G, sizeof(double) * e.C * e.nn, hipMemcpyHostToDevice)); e.gt_valid = false; return 0;
 }
 int dqmc_get_logdet(dqmc_engine* h, double* ld) {
     CHECK_E(h); Engine& e = h->e; DQ_HIP(hipSetDevice(e.device)); DQ_TRY(e.sync_and_check());

@@ -137,6 +137,7 @@ __global__ __launch_bounds__(256) void gemm_splitk_kernel(GemmDesc g, int tiles_
         double* dst = C + (i0 + r) + (long)n * j;
         if (g.accumulate) v += *dst;
         *dst = v;
+        if (g.CT.p) g.CT.at(chain)[j + (long)n * (i0 + r)] = v;       // transposed copy for the local-update walk (G -> GT)
     }
 }
 
@@ -234,7 +235,16 @@ static void launch_splitk(const GemmDesc& g, int n_chains, hipStream_t s) {
     else hipLaunchKernelGGL((gemm_splitk_kernel<false, KQ>), grid, block, 0, s, g, tiles);
 }
 
+static int launch_gemm_main(const GemmDesc& g, int n_chains, hipStream_t s, bool* ct_done);
+
 int launch_gemm(const GemmDesc& g, int n_chains, hipStream_t s) {
+    bool ct_done = false;
+    if (int rc = launch_gemm_main(g, n_chains, s, &ct_done)) return rc;
+    if (g.CT.p && !ct_done) return launch_transpose_scale(CMat(g.C.p, g.C.stride), g.CT, CVec(), g.n, n_chains, s);
+    return 0;
+}
+
+static int launch_gemm_main(const GemmDesc& g, int n_chains, hipStream_t s, bool* ct_done) {
     const int n = g.n;
     static const bool force_v1 = getenv("DQMC_GEMM_V1") != nullptr;      // A/B switch
     static const bool no_tile64 = getenv("DQMC_GEMM_NO_TILE64") != nullptr;
@@ -256,6 +266,7 @@ int launch_gemm(const GemmDesc& g, int n_chains, hipStream_t s) {
         else if (kq <= 128) launch_splitk<128>(g, n_chains, s);
         else launch_splitk<160>(g, n_chains, s);
         DQ_HIP(hipGetLastError());
+        *ct_done = true;
         return 0;
     }
     const int tiles = (n + 31) / 32;

@@ -694,7 +694,7 @@ int launch_update_slice(const UpdateDesc& d, int l, int acc_slot, int n_chains, 
     const int tiles = (n + 31) / 32;
     if (regs) {
         if (!d.GT.p) { set_error("local update: transposed workspace missing"); return -1; }
-        if (int rc = launch_transpose_scale(CMat(d.G.p, d.G.stride), d.GT, CVec(), n, n_chains, s)) return rc;      // GT = G^T, kept in step by the flushes
+        if (!d.gt_valid) { if (int rc = launch_transpose_scale(CMat(d.G.p, d.G.stride), d.GT, CVec(), n, n_chains, s)) return rc; }      // GT = G^T, kept in step by the flushes
     }
     static const bool multi_kernel = getenv("DQMC_SLICE_MULTIKERNEL") != nullptr;      // A/B switch
     // persistent single-launch path: needs every workgroup of a chain resident at once, one per CU (the walk's LDS)

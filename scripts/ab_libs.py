@@ -16,6 +16,8 @@ for _ in range(3):
     e0.sweep_0_to_beta(*m.random_stream(rng)); e0.sweep_beta_to_0(*m.random_stream(rng))
 fields = e0.get_fields(); del e0
 streams = [m.random_stream(np.random.default_rng(100 + i)) for i in range(2 * nsw)]
+if os.environ.get("AB_NOACC"):      # u = 1: no proposal is ever accepted -> the fixed cost of a slice
+    streams = [(p_, k_, np.ones_like(u_)) for (p_, k_, u_) in streams]
 res = {p: [] for p in paths}
 for rep in range(3):
     for p in paths:
