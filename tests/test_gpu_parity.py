@@ -350,24 +350,33 @@ def test_set_G_and_reinit_are_consistent(hip, orc):
 
 
 def test_alternative_kernel_paths_in_subprocess(hip):
-    """The opt-in / fallback kernels (cooperative 8-workgroup QRCP, streaming QRCP, streaming LU, one-wave-per-tile GEMM)
+    """The opt-in / fallback kernels (cooperative 8-workgroup QRCP, block-cyclic QRCP, streaming QRCP, streaming LU, one-wave-per-tile
+    GEMM, scan / flush kernel pairs instead of the single-launch slice kernel)
     are selected by environment switches read once per process: run them in child processes and check cfg-3 init parity
     against the default path (itself checked against the oracle above)."""
     import subprocess, sys, json
     code = ("import sys, json, numpy as np; sys.path.insert(0, %r); import dqmc_amd; "
             "m = dqmc_amd.HubbardModel(**dqmc_amd.CONFIGS['cfg3']); e = m.engine(dqmc_amd.lib()); "
-            "e.set_fields(m.random_fields(12)); e.init(); G = e.get_G(); "
-            "print(json.dumps({'ld': e.get_logdet(), 'g00': float(G[0, 0]), 'sum': float(np.abs(G).sum())}))") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+            "e.set_fields(m.random_fields(12)); e.init(); G = e.get_G(); rng = np.random.default_rng(5); acc = []\n"
+            "for l in range(3):\n"
+            "    e.wrap_forward(l); acc.append(int(e.local_update_slice(l, *m.random_stream(rng, 1))))\n"
+            "G2 = e.get_G(); f = e.get_fields()\n"
+            "print(json.dumps({'ld': e.get_logdet(), 'g00': float(G[0, 0]), 'sum': float(np.abs(G).sum()), 'acc': acc, "
+            "'sum2': float(np.abs(G2).sum()), 'fsum': int((f[:3] * np.arange(1, f.shape[1] + 1)).sum())}))") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     def run(env_extra):
         env = dict(os.environ); env.update(env_extra)
         out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
         assert out.returncode == 0, out.stderr[-2000:]
         return json.loads(out.stdout.strip().splitlines()[-1])
     ref = run({})
-    for env in ({"DQMC_QR_COOP": "1"}, {"DQMC_QR_STREAMING": "1"}, {"DQMC_LU_STREAMING": "1"}, {"DQMC_GEMM_V1": "1"}):
+    for env in ({"DQMC_QR_COOP": "1"}, {"DQMC_QR_BLOCKCYCLIC": "1"}, {"DQMC_QR_STREAMING": "1"}, {"DQMC_LU_STREAMING": "1"}, {"DQMC_GEMM_V1": "1"},
+                {"DQMC_SLICE_MULTIKERNEL": "1"}):
         got = run(env)
         assert abs(got["ld"] - ref["ld"]) < 1e-8 * abs(ref["ld"]), (env, got, ref)
         assert abs(got["sum"] - ref["sum"]) < 1e-7 * abs(ref["sum"]), (env, got, ref)
+        # three slices of wrap + local update (single-launch slice kernel vs scan / flush pairs, every factorisation variant)
+        assert got["acc"] == ref["acc"] and got["fsum"] == ref["fsum"], (env, got, ref)
+        assert abs(got["sum2"] - ref["sum2"]) < 1e-7 * abs(ref["sum2"]), (env, got, ref)
 
 
 def test_error_codes(hip):
