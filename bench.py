@@ -69,11 +69,14 @@ def main():
     ap.add_argument("--batched-chains", type=int, default=64,
                     help="also time this many chains batched on one GPU (N=1 only; 0 disables); reported beside `value`, never as `value`")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
+    ap.add_argument("--rehearse-shared-gpu", action="store_true",
+                    help="functional rehearsal of the N > 1 path on a box with fewer GPUs than ranks: gloo rendezvous, ranks share devices "
+                         "(local_rank %% device_count); the timing is meaningless")
     args = ap.parse_args()
 
     import torch
     from dqmc_amd.launch import barrier as dist_barrier, dist_init, finalize, max_over_ranks
-    d = dist_init()                       # WORLD_SIZE > 1: backend "nccl" (= RCCL) on GPUs
+    d = dist_init("gloo" if args.rehearse_shared_gpu else None)      # WORLD_SIZE > 1: backend "nccl" (= RCCL) on GPUs
     rank, world, local_rank = d.rank, d.world, d.local_rank
 
     import dqmc_amd
@@ -82,7 +85,7 @@ def main():
         raise SystemExit("bench.py needs a GPU: the HIP library has no CPU fallback")
     model = dqmc_amd.HubbardModel(**dqmc_amd.CONFIGS[args.config])
     C = args.chains_per_gpu
-    eng = model.engine(lib, device=local_rank, n_chains=C)
+    eng = model.engine(lib, device=(local_rank % lib.device_count()) if args.rehearse_shared_gpu else local_rank, n_chains=C)
     fields = np.stack([model.random_fields(12345 + rank * C + c) for c in range(C)])
     eng.set_fields(fields); eng.init()
     rng = np.random.default_rng(777 + rank)

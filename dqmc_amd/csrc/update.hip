@@ -221,9 +221,13 @@ __device__ __forceinline__ void walk_load_group(double (&pc)[8], double (&pr)[8]
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         const int i = sh.site[min(g * 8 + q, n - 1)];             // clamped: loads stay unconditional
-        const long off = jj + (long)n * i;
-        if (COH) { pc[q] = ld_coh(G + off); pr[q] = ld_coh(GT + off); }
-        else { pc[q] = G[off]; pr[q] = GT[off]; }
+        // 32-bit byte offset from a wave-uniform base: the loads take the (SGPR base + VGPR offset) form, one VALU
+        // instruction per address pair instead of two 64-bit multiply-adds
+        const unsigned off8 = (unsigned)(jj + n * i) * 8u;
+        const double* gp = reinterpret_cast<const double*>(reinterpret_cast<const char*>(G) + off8);
+        const double* tp = reinterpret_cast<const double*>(reinterpret_cast<const char*>(GT) + off8);
+        if (COH) { pc[q] = ld_coh(gp); pr[q] = ld_coh(tp); }
+        else { pc[q] = *gp; pr[q] = *tp; }
     }
 }
 __device__ __forceinline__ d16v vec_set(d16v v, int q, double x) { v[q] = x; return v; }
