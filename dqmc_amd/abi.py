@@ -47,6 +47,7 @@ ABI_SYMBOLS = [
     "n_stack", "get_stack", "sweep_0_to_beta", "sweep_beta_to_0", "sync", "get_stats",
     "wrap_forward", "wrap_backward", "local_update_slice", "calculate_Bbar", "global_action",
     "update_kernel_time", "set_profiling",
+    "measure_equal_time", "measure_accumulate", "measure_fetch",
 ]
 
 
@@ -95,6 +96,10 @@ class DqmcLib:
         g("calculate_Bbar").argtypes = [C.c_void_p, C.c_int, c_double_p]
         g("update_kernel_time").argtypes = [C.c_void_p, c_double_p, c_int64_p, c_int64_p]
         g("set_profiling").argtypes = [C.c_void_p, C.c_int]
+        if self.has_symbol("measure_equal_time"):
+            g("measure_equal_time").argtypes = [C.c_void_p, C.c_int, C.c_int, c_double_p, c_double_p]
+            g("measure_accumulate").argtypes = [C.c_void_p, C.c_int, C.c_int]
+            g("measure_fetch").argtypes = [C.c_void_p, c_double_p, c_double_p, c_int64_p, C.c_int]
         g("to_ldr").argtypes = [C.c_int] + [c_double_p] * 4
         g("ldr_mul_mat").argtypes = [C.c_int] + [c_double_p] * 7
         g("mat_mul_ldr").argtypes = [C.c_int] + [c_double_p] * 7
@@ -304,6 +309,23 @@ class Engine:
 
     def global_action(self):
         v = np.zeros(self.C); self._c("global_action", _p(v)); return v if self.batched else float(v[0])
+
+    # ---- equal-time observables ----
+    def measure_equal_time(self, L1: int, L2: int):
+        """(scalars[3] = density, doubleOcc, swave; chi_r[L1, L2]) of the current G; leading chain axis when batched."""
+        sc = np.empty((self.C, 3)); chi = np.empty((self.C, L1 * L2))
+        self._c("measure_equal_time", int(L1), int(L2), _p(sc), _p(chi))
+        chi = chi.reshape(self.C, L2, L1).transpose(0, 2, 1)            # element (dx_idx, dy_idx) at dx_idx + L1*dy_idx
+        return (sc, chi) if self.batched else (sc[0], chi[0])
+
+    def measure_accumulate(self, L1: int, L2: int):
+        self._c("measure_accumulate", int(L1), int(L2))
+
+    def measure_fetch(self, L1: int, L2: int, reset: bool = True):
+        sc = np.empty((self.C, 3)); chi = np.empty((self.C, L1 * L2)); cnt = np.zeros(1, dtype=np.int64)
+        self._c("measure_fetch", _p(sc), _p(chi), cnt.ctypes.data_as(c_int64_p), 1 if reset else 0)
+        chi = chi.reshape(self.C, L2, L1).transpose(0, 2, 1)
+        return ((sc, chi) if self.batched else (sc[0], chi[0])) + (int(cnt[0]),)
 
     def set_profiling(self, on: bool):
         self._c("set_profiling", int(bool(on)))

@@ -6,6 +6,7 @@
 // TermA + TermB sum (:151) and the wrap-vs-stabilised max|dG|
 // (DQMC::check_error, source/dqmc.cpp:317-329).  blockIdx.y = chain.
 #include "common.h"
+#include "wave.h"
 
 namespace dq {
 
@@ -183,6 +184,66 @@ __global__ void fold_stats_kernel(DevStats* st, const int* acc, long acc_stride,
 int launch_fold_stats(DevStats* st, const int* acc, long acc_stride, int n_slices, const double* err, long err_stride, int n_err,
                       int n, int nt, int n_chains, hipStream_t s) {
     hipLaunchKernelGGL(fold_stats_kernel, dim3((n_chains + 63) / 64), dim3(64), 0, s, st, acc, acc_stride, n_slices, err, err_stride, n_err, n, nt, n_chains);
+    DQ_HIP(hipGetLastError());
+    return 0;
+}
+
+
+// ---- equal-time observables -------------------------------------------------------------------
+// One workgroup per chain, thread t <-> site t AND displacement bin t (n_orb = 1: L1*L2 bins = n sites).
+//   density   = (1/N) sum_i 2 (1 - G_ii)                                  source/model.cpp:167-192
+//   doubleOcc = (1/N) sum_i (1 - G_ii)^2                                  :195-220
+//   swave     = (1/N) sum_ij (delta_ji - G_ji)^2                          :222-256
+//   ninj(i,j) = n_i n_j + 2 (1 - G_ji) G_ij - n_avg^2, n_i = 2 (1 - G_ii) :258-288 (the "1 -" is literal in the reference, also for i != j)
+//   chi_r(d)  = (1/N) sum_i ninj(i, i + d)                                include/measurementh5.h:20-66
+// Every bin is summed by one thread in a fixed order (no atomics): results are reproducible run to run.
+__global__ __launch_bounds__(1024) void measure_equal_time_kernel(CMat Gm, double* out_p, long out_stride, int L1, int L2, int accumulate) {
+    __shared__ double red[3][16];
+    __shared__ double s_navg;
+    const int chain = blockIdx.y;
+    const int n = L1 * L2;
+    const double* __restrict__ G = Gm.at(chain);
+    double* out = out_p + (long)chain * out_stride;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, nwaves = (blockDim.x + 63) >> 6;
+    double dens = 0.0, docc = 0.0, sw = 0.0;
+    if (t < n) {
+        const double c = 1.0 - G[t + (long)n * t];
+        dens = 2.0 * c; docc = c * c;
+        for (int j = 0; j < n; ++j) { const double x = (j == t ? 1.0 : 0.0) - G[j + (long)n * t]; sw += x * x; }   // column t: contiguous
+    }
+    dens = wave_sum(dens); docc = wave_sum(docc); sw = wave_sum(sw);
+    if (lane == 0) { red[0][wave] = dens; red[1][wave] = docc; red[2][wave] = sw; }
+    __syncthreads();
+    if (t == 0) {
+        double a = 0.0, b = 0.0, c = 0.0;
+        for (int q = 0; q < nwaves; ++q) { a += red[0][q]; b += red[1][q]; c += red[2][q]; }
+        a /= n; b /= n; c /= n;
+        s_navg = a;                                            // n_avg of calculate_densityCorr == density
+        if (accumulate) { out[0] += a; out[1] += b; out[2] += c; } else { out[0] = a; out[1] = b; out[2] = c; }
+    }
+    __syncthreads();
+    if (t < n) {
+        // bin t = (dx_idx, dy_idx) = (t % L1, t / L1); displacement d = idx - (L/2 - 1) in (-L/2, L/2]
+        const int dx = (t % L1) - (L1 / 2 - 1), dy = (t / L1) - (L2 / 2 - 1);
+        const double navg = s_navg;
+        double acc = 0.0;
+        for (int i = 0; i < n; ++i) {
+            const int xi = i % L1, yi = i / L1;
+            const int xj = ((xi + dx) % L1 + L1) % L1, yj = ((yi + dy) % L2 + L2) % L2;
+            const int j = yj * L1 + xj;
+            const double ni = 2.0 * (1.0 - G[i + (long)n * i]), nj = 2.0 * (1.0 - G[j + (long)n * j]);
+            acc += ni * nj + 2.0 * (1.0 - G[j + (long)n * i]) * G[i + (long)n * j] - navg * navg;
+        }
+        acc /= n;
+        if (accumulate) out[3 + t] += acc; else out[3 + t] = acc;
+    }
+}
+
+int launch_measure_equal_time(CMat G, double* out, long out_stride, int L1, int L2, int accumulate, int n_chains, hipStream_t s) {
+    const int n = L1 * L2;
+    if (n < 1 || n > 1024) { set_error("measure_equal_time: L1*L2 must be in 1..1024"); return -1; }
+    const int threads = ((n + 63) / 64) * 64;
+    hipLaunchKernelGGL(measure_equal_time_kernel, dim3(1, n_chains), dim3(threads), 0, s, G, out, out_stride, L1, L2, accumulate);
     DQ_HIP(hipGetLastError());
     return 0;
 }

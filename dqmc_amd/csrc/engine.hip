@@ -184,6 +184,8 @@ struct Engine {
     double* Upanel = nullptr; double* Wpanel = nullptr;          // [C][KD][n]
     int* state = nullptr;                                        // [C][4]
     double* prep = nullptr;                                      // [C][4n]
+    double* meas_now = nullptr; double* meas_sum = nullptr;      // [C][3 + n] equal-time observables: last evaluation / bin sums
+    long long meas_count = 0;                                    // measurements accumulated in meas_sum
     char* slice_sync = nullptr;                                  // [C][64 B] hand-off words of the persistent slice kernel
     int* acc = nullptr;                                          // [C][nt]
     double* err = nullptr;                                       // [C][n_stack]
@@ -210,7 +212,7 @@ struct Engine {
         if (s) (void)hipStreamSynchronize(s);
         for (auto& p : ev_pairs) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
         if (stage_free) (void)hipEventDestroy(stage_free);
-        void* ptrs[] = {GT, slice_sync, prep, stackP, expK, invexpK, fields, expv, invexpv, tabs, tab8, G, Gtmp, bb0, bb1, stackL, stackD, stackR, tmpL, tmpD, tmpR,
+        void* ptrs[] = {meas_now, meas_sum, GT, slice_sync, prep, stackP, expK, invexpK, fields, expv, invexpv, tabs, tab8, G, Gtmp, bb0, bb1, stackL, stackD, stackR, tmpL, tmpD, tmpR,
                         logdet, rs_perm, rs_k, rs_u, Upanel, Wpanel, state, acc, err, dstats, r1scratch};
         for (void* p : ptrs) if (p) (void)hipFree(p);
         if (h_stage) (void)hipHostFree(h_stage);
@@ -236,7 +238,7 @@ struct Engine {
         DQ_TRY(dalloc(&logdet, C));
         DQ_TRY(dalloc(&rs_perm, (size_t)C * nt * n)); DQ_TRY(dalloc(&rs_k, (size_t)C * nt * n)); DQ_TRY(dalloc(&rs_u, (size_t)C * nt * n));
         DQ_TRY(dalloc(&Upanel, (size_t)C * UPDATE_KD * n)); DQ_TRY(dalloc(&Wpanel, (size_t)C * UPDATE_KD * n));
-        DQ_TRY(dalloc(&state, (size_t)C * 4)); DQ_TRY(dalloc(&prep, (size_t)C * 4 * n)); DQ_TRY(dalloc(&slice_sync, (size_t)C * 64)); DQ_HIP(hipMemsetAsync(slice_sync, 0, (size_t)C * 64, s)); DQ_TRY(dalloc(&acc, (size_t)C * nt)); DQ_TRY(dalloc(&err, (size_t)C * n_stack));
+        DQ_TRY(dalloc(&state, (size_t)C * 4)); DQ_TRY(dalloc(&prep, (size_t)C * 4 * n)); DQ_TRY(dalloc(&meas_now, (size_t)C * (3 + n))); DQ_TRY(dalloc(&meas_sum, (size_t)C * (3 + n))); DQ_HIP(hipMemsetAsync(meas_sum, 0, sizeof(double) * C * (3 + n), s)); DQ_TRY(dalloc(&slice_sync, (size_t)C * 64)); DQ_HIP(hipMemsetAsync(slice_sync, 0, (size_t)C * 64, s)); DQ_TRY(dalloc(&acc, (size_t)C * nt)); DQ_TRY(dalloc(&err, (size_t)C * n_stack));
         DQ_TRY(dalloc(&dstats, C)); DQ_TRY(dalloc(&r1scratch, (size_t)C * (2 * n + 1)));
         h_stage_bytes = (size_t)C * nt * n * (sizeof(int32_t) + sizeof(uint8_t) + sizeof(double));
         DQ_HIP(hipHostMalloc(&h_stage, h_stage_bytes, hipHostMallocDefault));
@@ -661,6 +663,38 @@ int dqmc_global_action(dqmc_engine* h, double* S) {
         }
         S[c] = -2.0 * ld[c] - (lb + lg);
     }
+    return 0;
+}
+int dqmc_measure_equal_time(dqmc_engine* h, int L1, int L2, double* scalars, double* chi_r) {
+    CHECK_E(h); Engine& e = h->e; DQ_HIP(hipSetDevice(e.device));
+    if (L1 < 1 || L2 < 1 || L1 * L2 != e.n) { set_error("measure_equal_time: L1*L2 must equal n_sites"); return DQMC_EINVAL; }
+    DQ_TRY(launch_measure_equal_time(CMat(e.G, e.nn), e.meas_now, 3 + e.n, L1, L2, 0, e.C, e.s));
+    DQ_TRY(e.sync_and_check());
+    std::vector<double> tmp((size_t)e.C * (3 + e.n));
+    DQ_HIP(hipMemcpy(tmp.data(), e.meas_now, sizeof(double) * tmp.size(), hipMemcpyDeviceToHost));
+    for (int c = 0; c < e.C; ++c) {
+        if (scalars) std::copy(tmp.begin() + (size_t)c * (3 + e.n), tmp.begin() + (size_t)c * (3 + e.n) + 3, scalars + 3 * (size_t)c);
+        if (chi_r) std::copy(tmp.begin() + (size_t)c * (3 + e.n) + 3, tmp.begin() + (size_t)(c + 1) * (3 + e.n), chi_r + (size_t)c * e.n);
+    }
+    return 0;
+}
+int dqmc_measure_accumulate(dqmc_engine* h, int L1, int L2) {
+    CHECK_E(h); Engine& e = h->e; DQ_HIP(hipSetDevice(e.device));
+    if (L1 < 1 || L2 < 1 || L1 * L2 != e.n) { set_error("measure_accumulate: L1*L2 must equal n_sites"); return DQMC_EINVAL; }
+    DQ_TRY(launch_measure_equal_time(CMat(e.G, e.nn), e.meas_sum, 3 + e.n, L1, L2, 1, e.C, e.s));     // asynchronous, in stream order after the sweep
+    ++e.meas_count;
+    return 0;
+}
+int dqmc_measure_fetch(dqmc_engine* h, double* scalars_sum, double* chi_r_sum, int64_t* n_measurements, int reset) {
+    CHECK_E(h); Engine& e = h->e; DQ_HIP(hipSetDevice(e.device)); DQ_TRY(e.sync_and_check());
+    std::vector<double> tmp((size_t)e.C * (3 + e.n));
+    DQ_HIP(hipMemcpy(tmp.data(), e.meas_sum, sizeof(double) * tmp.size(), hipMemcpyDeviceToHost));
+    for (int c = 0; c < e.C; ++c) {
+        if (scalars_sum) std::copy(tmp.begin() + (size_t)c * (3 + e.n), tmp.begin() + (size_t)c * (3 + e.n) + 3, scalars_sum + 3 * (size_t)c);
+        if (chi_r_sum) std::copy(tmp.begin() + (size_t)c * (3 + e.n) + 3, tmp.begin() + (size_t)(c + 1) * (3 + e.n), chi_r_sum + (size_t)c * e.n);
+    }
+    if (n_measurements) *n_measurements = e.meas_count;
+    if (reset) { DQ_HIP(hipMemset(e.meas_sum, 0, sizeof(double) * tmp.size())); e.meas_count = 0; }
     return 0;
 }
 int dqmc_update_kernel_time(dqmc_engine* h, double* ms, int64_t* n_launches, int64_t* n_accepted) {

@@ -90,9 +90,13 @@ __device__ __forceinline__ void co_barrier() {
 #ifdef DQ_QR_STAMPS
 #define CST(v) { unsigned long long _t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t) :: "memory"); v = _t; }
 #define CACC(i, a, b) prof[i] += b - a;
+#define CST_DECL unsigned long long c0, c1, c2, c3, c4, c5, c6, c7;
+#define CST_TAIL { unsigned long long c8; CST(c8) CACC(7, c7, c8) }
 #else
 #define CST(v)
 #define CACC(i, a, b)
+#define CST_DECL
+#define CST_TAIL
 #endif
 
 struct CoShared {
@@ -214,7 +218,7 @@ __global__ __launch_bounds__(CO_T) __attribute__((amdgpu_num_vgpr(32))) void qrc
         constexpr int act = CO_ACT(JB);                                                                                               \
         const int k_end = min(16 * (JB) + 16, n);                                                                                     \
         for (int k = 16 * (JB); k < k_end; ++k) {                                                                                     \
-            unsigned long long c0, c1, c2, c3, c4, c5, c6, c7; CST(c0)                                                                \
+            CST_DECL CST(c0)                                                                \
             /* ---- pivot: largest partial column norm (the keys of the four waves of the half that owned row k - 1) ---- */          \
             CO_IDS                                                                                                                    \
             const bool upd = sh.livec[col] != 0;           /* the reflector touches live columns, the pivot column included */       \
@@ -344,7 +348,7 @@ __global__ __launch_bounds__(CO_T) __attribute__((amdgpu_num_vgpr(32))) void qrc
                     if (lane == 0) sh.keys[wave & 3] = key;                                                                           \
                 }                                                                                                                     \
                 co_barrier();                                                                                                         \
-                { unsigned long long c8; CST(c8) CACC(7, c7, c8) }                                                                    \
+                CST_TAIL                                                                    \
             }                                                                                                                         \
         }                                                                                                                             \
     }

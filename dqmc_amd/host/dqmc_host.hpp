@@ -400,6 +400,24 @@ public:
     void sweep_beta_to_0(std::vector<GF>&, std::vector<LDRStack>&) { draw_half_sweep(false); dqmc_detail::check(dqmc_sweep_beta_to_0(e_, perm_.data(), kprop_.data(), u_.data())); }
     void sweep_unequalTime(std::vector<GF>&, std::vector<LDRStack>&) {}          // out of scope; no-op as with isMeasureUnequalTime=false (source/dqmc.cpp:461-463)
     double global_action() { double S; dqmc_detail::check(dqmc_global_action(e_, &S)); return S; }   // source/model.cpp:140-159
+    // ---- equal-time observables on the device (source/model.cpp:167-288, include/measurementh5.h:13-66) ----
+    struct EqualTime { double density = 0, doubleOcc = 0, swave = 0; std::vector<double> densityCorr_r; long long n = 0; };
+    // one evaluation on the current Gtt[0] (what measurements.measure(greens, lat) computes, source/main.cpp:165)
+    EqualTime measure_equal_time(const Lattice& lat) {
+        EqualTime m; double sc[3]; m.densityCorr_r.resize((size_t)lat.L1() * lat.L2());
+        dqmc_detail::check(dqmc_measure_equal_time(e_, lat.L1(), lat.L2(), sc, m.densityCorr_r.data()));
+        m.density = sc[0]; m.doubleOcc = sc[1]; m.swave = sc[2]; m.n = 1; return m;
+    }
+    // bin accumulation: measure() per sweep stays on the device (asynchronous), fetch_bin() returns the bin AVERAGES and starts a new bin
+    void measure(const Lattice& lat) { dqmc_detail::check(dqmc_measure_accumulate(e_, lat.L1(), lat.L2())); }
+    EqualTime fetch_bin(const Lattice& lat) {
+        EqualTime m; double sc[3]; int64_t cnt = 0; m.densityCorr_r.resize((size_t)lat.L1() * lat.L2());
+        dqmc_detail::check(dqmc_measure_fetch(e_, sc, m.densityCorr_r.data(), &cnt, 1));
+        const double inv = cnt > 0 ? 1.0 / (double)cnt : 0.0;
+        m.density = sc[0] * inv; m.doubleOcc = sc[1] * inv; m.swave = sc[2] * inv; m.n = cnt;
+        for (double& x : m.densityCorr_r) x *= inv;
+        return m;
+    }
 };
 
 namespace update {

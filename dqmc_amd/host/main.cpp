@@ -2,7 +2,8 @@
 // host facade: read ./parameters.in (or argv[1]), build Lattice / AttractiveHubbard / DQMC,
 // thermalise, sweep, report time, acceptance and wrap error.  One process = one Markov chain on one
 // GPU (the reference's MPI rank); the multi-GPU launcher and replica exchange over RCCL are in
-// bench.py / dqmc_amd/replica.py.  Measurements (Observables, HDF5) are out of scope.
+// bench.py / dqmc_amd/replica.py.  Equal-time observables are accumulated per bin on the device and
+// printed; the HDF5 writers stay out of scope.
 #include "dqmc_host.hpp"
 
 #include <chrono>
@@ -48,7 +49,13 @@ int main(int argc, char** argv) {
             sim.sweep_0_to_beta(greens, propagation_stacks);
             sim.sweep_beta_to_0(greens, propagation_stacks);
             sim.sweep_unequalTime(greens, propagation_stacks);
-            if (isweep % n_sweeps == 0) sim.download(greens[0]);      // where measurements.accumulate would read Gtt[0]
+            sim.measure(lat);                                          // measurements.measure(greens, lat), source/main.cpp:165 -- on the device, asynchronous
+            if (isweep % n_sweeps == 0) {                              // measurements.accumulate(lat), :167-169: one bin done
+                const DQMC::EqualTime bin = sim.fetch_bin(lat);
+                std::cout << "bin " << isweep / n_sweeps << " (" << bin.n << " sweeps): density " << std::setprecision(8) << bin.density
+                          << "  doubleOcc " << bin.doubleOcc << "  swave " << bin.swave << "  densityCorr(r=0) "
+                          << bin.densityCorr_r[(size_t)(lat.L1() / 2 - 1) + (size_t)lat.L1() * (lat.L2() / 2 - 1)] << '\n';
+            }
         }
         sim.download(greens[0]);
         const double local_time = std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();

@@ -192,6 +192,23 @@ int dqmc_calculate_Bbar(dqmc_engine* e, int i_stack, double* Bbar);
 /* AttractiveHubbard::global_action (source/model.cpp:140-159).               */
 int dqmc_global_action(dqmc_engine* e, double* S);
 
+/* ---- equal-time observables on the device ---------------
+ * Observables::calculate_density / calculate_doubleOccupancy / calculate_swavePairing /
+ * calculate_densityCorr (source/model.cpp:167-288) of the current G = Gtt[0] (what
+ * measurements.measure reads after sweep_beta_to_0, source/main.cpp:165), the site
+ * matrix of densityCorr reduced to displacement space exactly as
+ * transform::chi_site_to_chi_r does (include/measurementh5.h:13-66, n_orb = 1):
+ *   scalars [n_chains][3] = density, doubleOcc, swave
+ *   chi_r   [n_chains][L1*L2], element (dx_idx, dy_idx) at dx_idx + L1*dy_idx,
+ *           dx_idx = pbc_shortest(xj - xi, L1) + L1/2 - 1 (likewise dy)
+ * L1*L2 must equal n_sites.  Avoids the N x N download per sweep.                */
+int dqmc_measure_equal_time(dqmc_engine* e, int L1, int L2, double* scalars, double* chi_r);
+/* Bin accumulation on the device (MeasurementManager::measure + accumulate,
+ * include/measurementh5.h:189-274): add the observables of the current G to the
+ * running sums / read sums and count back, optionally starting a new bin.        */
+int dqmc_measure_accumulate(dqmc_engine* e, int L1, int L2);
+int dqmc_measure_fetch(dqmc_engine* e, double* scalars_sum, double* chi_r_sum, int64_t* n_measurements, int reset);
+
 /* Number of accepted proposals / kernel time (ms, HIP events on the engine's
  * stream) spent inside the local-update kernels since the last call -- the
  * live measurement bench.py uses for the rank-1 roofline.                    */

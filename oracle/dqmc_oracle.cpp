@@ -480,6 +480,43 @@ struct Engine {
         for (int i = 0; i < n; ++i) for (int l = 0; l < nt; ++l) { const int f = fields[(size_t)l * n + i]; lb += alpha * g * eta[f]; lg += std::log(gamma[f]); }
         S -= lb + lg; return S;
     }
+    /* ---- equal-time observables ---------------------------------
+     * Observables::calculate_density :167-192, calculate_doubleOccupancy :195-220,
+     * calculate_swavePairing :222-256, calculate_densityCorr :258-288 of source/model.cpp on
+     * Gtt[0] (Gup == Gdn), then transform::chi_site_to_chi_r (include/measurementh5.h:13-66,
+     * n_orb = 1): loops and summation order of the reference are kept.                    */
+    static int pbc_shortest(int d, int L) { if (d > L / 2) d -= L; if (d <= -L / 2) d += L; return d; }      // measurementh5.h:13-17
+    void measure_equal_time(int L1, int L2, double* scalars, double* chi_r) const {
+        auto Gc = [&](int i, int j) { return (i == j ? 1.0 : 0.0) - G[i + (size_t)n * j]; };                  // eye - G
+        double density = 0.0, d_occ = 0.0, swave = 0.0;
+        for (int i = 0; i < n; ++i) density += Gc(i, i) + Gc(i, i);
+        density /= n;
+        for (int i = 0; i < n; ++i) d_occ += Gc(i, i) * Gc(i, i);
+        d_occ /= n;
+        for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) swave += Gc(j, i) * Gc(j, i);
+        swave /= n;
+        scalars[0] = density; scalars[1] = d_occ; scalars[2] = swave;
+        double n_avg = 0.0;
+        for (int i = 0; i < n; ++i) n_avg += 2.0 * (1.0 - G[i + (size_t)n * i]);
+        n_avg /= n;
+        vecd ninj((size_t)n * n);
+        for (int i = 0; i < n; ++i) {
+            const double n_i = 2.0 * (1.0 - G[i + (size_t)n * i]);
+            for (int j = 0; j < n; ++j) {
+                const double n_j = 2.0 * (1.0 - G[j + (size_t)n * j]);
+                const double exchange = 2.0 * (1.0 - G[j + (size_t)n * i]) * G[i + (size_t)n * j];           // "1.0 -" also off the diagonal: as written in :280
+                ninj[i + (size_t)n * j] = n_i * n_j + exchange - n_avg * n_avg;
+            }
+        }
+        std::fill(chi_r, chi_r + (size_t)L1 * L2, 0.0);
+        for (int ij = 0; ij < n * n; ++ij) {                                                                   // measurementh5.h:36-62, n_cells = n
+            const int i = ij % n, j = ij / n;
+            const int cxi = i % L1, cyi = i / L1, cxj = j % L1, cyj = j / L1;
+            const int dx_idx = pbc_shortest(cxj - cxi, L1) + L1 / 2 - 1, dy_idx = pbc_shortest(cyj - cyi, L2) + L2 / 2 - 1;
+            chi_r[dx_idx + (size_t)L1 * dy_idx] += ninj[i + (size_t)n * j] / n;
+        }
+    }
+    vecd meas_sum; long long meas_count = 0;
 };
 constexpr int Engine::proposal[4][3];
 
@@ -546,6 +583,27 @@ int orc_wrap_backward(orc_engine* e, int l) { if (l < 0 || l >= e->nt) return fa
 int orc_local_update_slice(orc_engine* e, int l, const int32_t* perm, const uint8_t* kprop, const double* u, int* accepted) { if (l < 0 || l >= e->nt) return fail(ERANGE_, "slice"); int a = e->local_update(l, perm, kprop, u); if (accepted) *accepted = a; return OK; }
 int orc_calculate_Bbar(orc_engine* e, int is, double* out) { if (is < 0 || is >= e->n_stack) return fail(ERANGE_, "stack index"); vecd bb; e->Bbar(is, bb); std::copy(bb.begin(), bb.end(), out); return OK; }
 int orc_global_action(orc_engine* e, double* S) { *S = e->global_action(); return OK; }
+int orc_measure_equal_time(orc_engine* e, int L1, int L2, double* scalars, double* chi_r) {
+    if (L1 < 1 || L2 < 1 || L1 * L2 != e->n) return fail(EINVAL_, "measure_equal_time: L1*L2 must equal n_sites");
+    double sc[3]; vecd chi((size_t)e->n); e->measure_equal_time(L1, L2, sc, chi.data());
+    if (scalars) std::copy(sc, sc + 3, scalars); if (chi_r) std::copy(chi.begin(), chi.end(), chi_r); return OK;
+}
+int orc_measure_accumulate(orc_engine* e, int L1, int L2) {
+    if (L1 < 1 || L2 < 1 || L1 * L2 != e->n) return fail(EINVAL_, "measure_accumulate: L1*L2 must equal n_sites");
+    if (e->meas_sum.empty()) e->meas_sum.assign(3 + (size_t)e->n, 0.0);
+    double sc[3]; vecd chi((size_t)e->n); e->measure_equal_time(L1, L2, sc, chi.data());
+    for (int q = 0; q < 3; ++q) e->meas_sum[q] += sc[q];
+    for (int q = 0; q < e->n; ++q) e->meas_sum[3 + q] += chi[q];
+    ++e->meas_count; return OK;
+}
+int orc_measure_fetch(orc_engine* e, double* scalars_sum, double* chi_r_sum, int64_t* n_meas, int reset) {
+    if (e->meas_sum.empty()) e->meas_sum.assign(3 + (size_t)e->n, 0.0);
+    if (scalars_sum) std::copy(e->meas_sum.begin(), e->meas_sum.begin() + 3, scalars_sum);
+    if (chi_r_sum) std::copy(e->meas_sum.begin() + 3, e->meas_sum.end(), chi_r_sum);
+    if (n_meas) *n_meas = e->meas_count;
+    if (reset) { std::fill(e->meas_sum.begin(), e->meas_sum.end(), 0.0); e->meas_count = 0; }
+    return OK;
+}
 int orc_update_kernel_time(orc_engine*, double* ms, int64_t* nl, int64_t* na) { if (ms) *ms = 0; if (nl) *nl = 0; if (na) *na = 0; return OK; }
 int orc_set_profiling(orc_engine*, int) { return OK; }
 

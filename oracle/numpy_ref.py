@@ -167,3 +167,25 @@ def free_fermion_G(model: HubbardModel):
             G += (np.outer(ph, ph.conj()) / (1.0 + np.exp(-model.beta * eps))).real
             logdet += np.log1p(np.exp(-model.beta * eps))
     return G, logdet
+
+
+def equal_time_observables(G, L1, L2):
+    """Independent numpy evaluation of the reference's equal-time observables (formulas of source/model.cpp:167-288, displacement
+    binning of include/measurementh5.h:13-66, n_orb = 1) -- vectorised, so the summation order differs from the loops the oracle keeps.
+    Returns (scalars[3] = density, doubleOcc, swave; chi_r[L1, L2] indexed [dx_idx, dy_idx])."""
+    G = np.asarray(G, dtype=np.float64); n = G.shape[0]
+    assert n == L1 * L2
+    Gc = np.eye(n) - G
+    dens = 2.0 * np.trace(Gc) / n
+    docc = np.sum(np.diag(Gc) ** 2) / n
+    swave = np.sum(Gc * Gc) / n
+    ni = 2.0 * (1.0 - np.diag(G))
+    ninj = np.outer(ni, ni) + 2.0 * (1.0 - G.T) * G - (ni.mean()) ** 2          # ninj[i, j]; (1 - G(j,i)) G(i,j)
+    x = np.arange(n) % L1; y = np.arange(n) // L1
+    def pbc(d, L):
+        d = np.where(d > L // 2, d - L, d); return np.where(d <= -(L // 2), d + L, d)
+    dx = pbc(x[None, :] - x[:, None], L1) + L1 // 2 - 1          # [i, j]
+    dy = pbc(y[None, :] - y[:, None], L2) + L2 // 2 - 1
+    chi = np.zeros((L1, L2))
+    np.add.at(chi, (dx, dy), ninj / n)
+    return np.array([dens, docc, swave]), chi

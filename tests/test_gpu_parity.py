@@ -379,6 +379,57 @@ def test_alternative_kernel_paths_in_subprocess(hip):
         assert abs(got["sum2"] - ref["sum2"]) < 1e-7 * abs(ref["sum2"]), (env, got, ref)
 
 
+# ---- equal-time observables on the device ------------------------------------------------------
+@pytest.mark.parametrize("shape", [(4, 4, 4.0, 2.0, 20), (8, 8, 4.0, 4.0, 80), (6, 4, 4.0, 3.0, 30), (16, 16, 8.0, 8.0, 200)])
+def test_observables_parity(hip, orc, shape):
+    """density / doubleOcc / swave / densityCorr(r) of the device against the oracle's restatement of source/model.cpp:167-288 +
+    include/measurementh5.h:13-66 after one sweep on both sides (fp64: 1e-10 relative to the largest entry), bins included."""
+    L1, L2, U, beta, nt = shape
+    m = HubbardModel(L1=L1, L2=L2, U=U, beta=beta, nt=nt, n_stab=10)
+    f0 = m.random_fields(21); rng = np.random.default_rng(8)
+    sf, sb = m.random_stream(rng), m.random_stream(rng)
+    e = m.engine(hip); o = m.engine(orc)
+    for x in (e, o):
+        x.set_fields(f0); x.init(); x.sweep_0_to_beta(*sf); x.sweep_beta_to_0(*sb)
+        x.measure_accumulate(L1, L2)
+    sc, chi = e.measure_equal_time(L1, L2); sco, chio = o.measure_equal_time(L1, L2)
+    scale = max(1.0, np.abs(chio).max(), np.abs(sco).max())
+    err = max(np.abs(sc - sco).max(), np.abs(chi - chio).max())
+    print(f"{L1}x{L2}: observables max err {err:.2e} (scale {scale:.2e})")
+    assert err < 1e-10 * scale and chi.shape == (L1, L2)
+    for x in (e, o):
+        x.sweep_0_to_beta(*sf); x.sweep_beta_to_0(*sb); x.measure_accumulate(L1, L2)
+    s1, c1, n1 = e.measure_fetch(L1, L2); s2, c2, n2 = o.measure_fetch(L1, L2)
+    assert n1 == n2 == 2 and max(np.abs(s1 - s2).max(), np.abs(c1 - c2).max()) < 2e-10 * scale
+    assert e.measure_fetch(L1, L2)[2] == 0                     # the fetch started a new bin
+    from dqmc_amd import DqmcError
+    with pytest.raises(DqmcError) as ei:
+        e.measure_equal_time(L1 + 1, L2)
+    assert ei.value.code == -1
+
+
+def test_observables_batched_and_golden(hip):
+    """Three chains in one engine give the three single-chain answers; on the committed fixtures the device reproduces the independent
+    numpy evaluation of the observables on the fixture's own G(0,0)."""
+    import oracle.numpy_ref as nr
+    m = HubbardModel(**CONFIGS["cfg2"])
+    fs = np.stack([m.random_fields(60 + c) for c in range(3)])
+    eb = m.engine(hip, n_chains=3); eb.set_fields(fs); eb.init()
+    scb, chib = eb.measure_equal_time(m.L1, m.L2)
+    for c in range(3):
+        e1 = m.engine(hip); e1.set_fields(fs[c]); e1.init()
+        s1, c1 = e1.measure_equal_time(m.L1, m.L2)
+        assert np.abs(scb[c] - s1).max() < 1e-12 and np.abs(chib[c] - c1).max() < 1e-12
+    for name in sorted(fn[:-4] for fn in os.listdir(GOLD) if fn.endswith(".npz")):
+        z = np.load(os.path.join(GOLD, name + ".npz"))
+        mg = HubbardModel(L1=int(z["L1"]), L2=int(z["L2"]), U=float(z["U"]), beta=float(z["beta"]), nt=int(z["nt"]), n_stab=int(z["n_stab"]))
+        e = mg.engine(hip); e.set_fields(z["fields"]); e.init()
+        sc, chi = e.measure_equal_time(mg.L1, mg.L2)
+        sc2, chi2 = nr.equal_time_observables(z["G0"], mg.L1, mg.L2)
+        scale = max(1.0, np.abs(chi2).max(), np.abs(z["G0"]).max() ** 2)
+        assert max(np.abs(sc - sc2).max(), np.abs(chi - chi2).max()) < float(z["tol"]) * 10 * scale, name
+
+
 def test_error_codes(hip):
     from dqmc_amd import DqmcError
     m = HubbardModel(**CONFIGS["cfg1"]); e = m.engine(hip); e.set_fields(m.random_fields(1))

@@ -136,3 +136,43 @@ def test_golden_vectors(orc, name):
         e.sweep_0_to_beta(z["perm_f"], z["k_f"], z["u_f"]); e.sweep_beta_to_0(z["perm_b"], z["k_b"], z["u_b"])
         assert (e.get_fields() == z["fields_after"]).all()
         assert np.abs(e.get_G() - z["G_after"]).max() < float(z["tol"]) * max(1.0, np.abs(z["G_after"]).max())
+
+
+# ---- equal-time observables -------------------------------------------------------------
+def test_observables_free_fermions_analytic(orc):
+    """U = 0: density, double occupancy and s-wave pairing have closed forms in k space
+    (n_k = 1/(e^{beta eps_k}+1), eps_k = -2t(cos kx + cos ky) - mu): density = (2/N) sum n_k, doubleOcc = (density/2)^2,
+    swave = (1/N) sum n_k^2 -- independent of how G was built."""
+    L1, L2, beta = 6, 4, 3.0
+    m = HubbardModel(L1=L1, L2=L2, U=0.0, beta=beta, nt=30, n_stab=10)
+    e = m.engine(orc); e.set_fields(m.random_fields(1)); e.init()
+    sc, chi = e.measure_equal_time(L1, L2)
+    kx = 2 * np.pi * np.arange(L1) / L1; ky = 2 * np.pi * np.arange(L2) / L2
+    eps = -2.0 * m.t * (np.cos(kx)[:, None] + np.cos(ky)[None, :]) - m.mu
+    nk = 1.0 / (np.exp(beta * eps) + 1.0)
+    dens = 2.0 * nk.mean()
+    assert abs(sc[0] - dens) < 1e-12 and abs(sc[1] - (dens / 2) ** 2) < 1e-12 and abs(sc[2] - (nk ** 2).mean()) < 1e-12
+    # translation invariance: the displacement-space sum reproduces any single row of the site matrix
+    sc2, chi2 = nr.equal_time_observables(e.get_G(), L1, L2)
+    assert np.abs(chi - chi2).max() < 1e-13 and chi.shape == (L1, L2)
+
+
+@pytest.mark.parametrize("cfg", ["cfg1", "cfg2"])
+def test_observables_vs_numpy(orc, cfg):
+    """The oracle keeps the reference's loops (source/model.cpp:167-288, include/measurementh5.h:13-66); numpy_ref evaluates the same
+    formulas vectorised.  Also the bin accumulation (sum of per-sweep values, count, reset)."""
+    m = HubbardModel(**CONFIGS[cfg]); rng = np.random.default_rng(3)
+    e = m.engine(orc); e.set_fields(m.random_fields(9)); e.init()
+    tot_s = np.zeros(3); tot_c = np.zeros((m.L1, m.L2))
+    for _ in range(2):
+        e.sweep_0_to_beta(*m.random_stream(rng)); e.sweep_beta_to_0(*m.random_stream(rng))
+        sc, chi = e.measure_equal_time(m.L1, m.L2)
+        sc2, chi2 = nr.equal_time_observables(e.get_G(), m.L1, m.L2)
+        assert np.abs(sc - sc2).max() < 1e-12 * max(1.0, np.abs(sc2).max()) and np.abs(chi - chi2).max() < 1e-12 * max(1.0, np.abs(chi2).max())
+        e.measure_accumulate(m.L1, m.L2); tot_s += sc; tot_c += chi
+    s_sum, c_sum, cnt = e.measure_fetch(m.L1, m.L2, reset=True)
+    assert cnt == 2 and np.abs(s_sum - tot_s).max() < 1e-12 and np.abs(c_sum - tot_c).max() < 1e-12
+    assert e.measure_fetch(m.L1, m.L2)[2] == 0
+    from dqmc_amd import DqmcError
+    with pytest.raises(DqmcError):
+        e.measure_equal_time(m.L1 + 1, m.L2)
