@@ -48,6 +48,7 @@ ABI_SYMBOLS = [
     "wrap_forward", "wrap_backward", "local_update_slice", "calculate_Bbar", "global_action",
     "update_kernel_time", "set_profiling",
     "measure_equal_time", "measure_accumulate", "measure_fetch",
+    "sweep_unequal_time", "get_G_tau",
 ]
 
 
@@ -100,6 +101,9 @@ class DqmcLib:
             g("measure_equal_time").argtypes = [C.c_void_p, C.c_int, C.c_int, c_double_p, c_double_p]
             g("measure_accumulate").argtypes = [C.c_void_p, C.c_int, C.c_int]
             g("measure_fetch").argtypes = [C.c_void_p, c_double_p, c_double_p, c_int64_p, C.c_int]
+        if self.has_symbol("sweep_unequal_time"):
+            g("sweep_unequal_time").argtypes = [C.c_void_p]
+            g("get_G_tau").argtypes = [C.c_void_p, C.c_int, C.c_int, c_double_p]
         g("to_ldr").argtypes = [C.c_int] + [c_double_p] * 4
         g("ldr_mul_mat").argtypes = [C.c_int] + [c_double_p] * 7
         g("mat_mul_ldr").argtypes = [C.c_int] + [c_double_p] * 7
@@ -326,6 +330,14 @@ class Engine:
         self._c("measure_fetch", _p(sc), _p(chi), cnt.ctypes.data_as(c_int64_p), 1 if reset else 0)
         chi = chi.reshape(self.C, L2, L1).transpose(0, 2, 1)
         return ((sc, chi) if self.batched else (sc[0], chi[0])) + (int(cnt[0]),)
+
+    # ---- unequal-time path ----
+    def sweep_unequal_time(self):
+        self._c("sweep_unequal_time")
+
+    def get_G_tau(self, which: str, l: int) -> np.ndarray:
+        """which in {"tt", "t0", "0t"}: Gtt[l], Gt0[l] = G(tau_l, 0), G0t[l] = G(0, tau_l) of the last sweep_unequal_time."""
+        B = np.empty(self.C * self.n * self.n); self._c("get_G_tau", {"tt": 0, "t0": 1, "0t": 2}[which], int(l), _p(B)); return self._mats_out(B)
 
     def set_profiling(self, on: bool):
         self._c("set_profiling", int(bool(on)))

@@ -70,6 +70,8 @@ int launch_split_d(CVec d, Vec dl_inv, Vec ds, double* logsum, int n, int n_chai
 // equal-time observables of G (source/model.cpp:167-288) in displacement space (include/measurementh5.h:13-66):
 // out[chain][0..2] = density, doubleOcc, swave; out[chain][3 + dx_idx + L1*dy_idx] = chi_r.  accumulate: out += (else out =)
 int launch_measure_equal_time(CMat G, double* out, long out_stride, int L1, int L2, int accumulate, int n_chains, hipStream_t s);
+// out = a * in + b * I (n x n)
+int launch_axpb_identity(CMat in, Mat out, double a, double b, int n, int n_chains, hipStream_t s);
 // out = in (n*n)
 int launch_copy(CMat in, Mat out, long count, int n_chains, hipStream_t s);
 // out = I

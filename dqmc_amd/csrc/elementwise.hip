@@ -248,4 +248,20 @@ int launch_measure_equal_time(CMat G, double* out, long out_stride, int L1, int 
     return 0;
 }
 
+
+// out = a * in + b * I: G(0,tau=0) = G - I, G(beta,0) = I - G, G(0,beta) = -G of the unequal-time path (source/dqmc.cpp:236-239, 271-275)
+__global__ void axpb_identity_kernel(CMat in, Mat out, double a, double b, int n) {
+    const int chain = blockIdx.y;
+    const double* x = in.at(chain);          // may alias out (in-place negation)
+    double* y = out.at(chain);
+    const long nn = (long)n * n;
+    for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < nn; k += (long)gridDim.x * blockDim.x)
+        y[k] = a * x[k] + ((k % n) == (k / n) ? b : 0.0);
+}
+int launch_axpb_identity(CMat in, Mat out, double a, double b, int n, int n_chains, hipStream_t s) {
+    hipLaunchKernelGGL(axpb_identity_kernel, dim3(64, n_chains), dim3(256), 0, s, in, out, a, b, n);
+    DQ_HIP(hipGetLastError());
+    return 0;
+}
+
 }  // namespace dq

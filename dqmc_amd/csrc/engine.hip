@@ -153,6 +153,20 @@ struct Ctx {
         DQ_TRY(launch_lu_solve(T(2), lperm(), n, T(3), CVec(), 0, n, C, stream));       // Y = M^-1 RHS
         return gemm(T(1), T(3), G);                                                     // G = X Y
     }
+    // stablelinalg::inv_invldr_plus_ldr (source/stablelinalg.cpp:160-190): G = [F1^-1 + F2]^-1 (negated on request)   (uses T0..T3, V0..V3)
+    int inv_invldr_plus_ldr(LdrRef F1, LdrRef F2, Mat G, bool negate) {
+        DQ_TRY(launch_split_d(F1.d, V(0), V(1), nullptr, n, C, stream));               // 1/D1l, D1s
+        DQ_TRY(launch_split_d(F2.d, V(2), V(3), nullptr, n, C, stream));               // 1/D2l, D2s
+        DQ_TRY(r_inverse_scaled(F2, V(2), T(1), T(0)));                                 // X = R2^-1 diag(1/D2l)
+        DQ_TRY(gemm(F1.L, T(1), T(2), V(0), CVec(), CVec(), 1));                        // TermA = diag(1/D1l) L1^T X
+        DQ_TRY(gemm(F1.R, F2.L, T(2), V(1), CVec(), V(3), 0, 1));                       // M = TermA + diag(D1s) R1 L2 diag(D2s)
+        DQ_TRY(launch_scale_rows(F1.R, V(1), T(3), n, C, stream));                      // RHS = diag(D1s) R1
+        DQ_TRY(launch_lu(T(2), lperm(), n, nullptr, 0, info(), n, C, stream, rowpos(), n));
+        DQ_TRY(launch_lu_solve(T(2), lperm(), n, T(3), CVec(), 0, n, C, stream));       // Y = M^-1 RHS
+        DQ_TRY(gemm(T(1), T(3), G));                                                    // G = X Y
+        if (negate) DQ_TRY(launch_axpb_identity(G, G, -1.0, 0.0, n, C, stream));
+        return 0;
+    }
 };
 
 // ---------------------------------------------------------------------------
@@ -185,6 +199,10 @@ struct Engine {
     int* state = nullptr;                                        // [C][4]
     double* prep = nullptr;                                      // [C][4n]
     double* meas_now = nullptr; double* meas_sum = nullptr;      // [C][3 + n] equal-time observables: last evaluation / bin sums
+    // unequal-time path (allocated by the first sweep_unequal): Gtt / Gt0 / G0t [nt + 1][C][nn], B(tau,0) ping-pong LDRs, scratch
+    double* utG[3] = {nullptr, nullptr, nullptr}; double* utTmp = nullptr; double* utErr = nullptr;
+    double* utL[2] = {nullptr, nullptr}; double* utD[2] = {nullptr, nullptr}; double* utR[2] = {nullptr, nullptr}; int* utP[2] = {nullptr, nullptr};
+    bool utTri[2] = {false, false}; bool ut_valid = false;
     long long meas_count = 0;                                    // measurements accumulated in meas_sum
     char* slice_sync = nullptr;                                  // [C][64 B] hand-off words of the persistent slice kernel
     int* acc = nullptr;                                          // [C][nt]
@@ -212,7 +230,7 @@ struct Engine {
         if (s) (void)hipStreamSynchronize(s);
         for (auto& p : ev_pairs) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
         if (stage_free) (void)hipEventDestroy(stage_free);
-        void* ptrs[] = {meas_now, meas_sum, GT, slice_sync, prep, stackP, expK, invexpK, fields, expv, invexpv, tabs, tab8, G, Gtmp, bb0, bb1, stackL, stackD, stackR, tmpL, tmpD, tmpR,
+        void* ptrs[] = {utG[0], utG[1], utG[2], utTmp, utErr, utL[0], utL[1], utD[0], utD[1], utR[0], utR[1], utP[0], utP[1], meas_now, meas_sum, GT, slice_sync, prep, stackP, expK, invexpK, fields, expv, invexpv, tabs, tab8, G, Gtmp, bb0, bb1, stackL, stackD, stackR, tmpL, tmpD, tmpR,
                         logdet, rs_perm, rs_k, rs_u, Upanel, Wpanel, state, acc, err, dstats, r1scratch};
         for (void* p : ptrs) if (p) (void)hipFree(p);
         if (h_stage) (void)hipHostFree(h_stage);
@@ -381,6 +399,52 @@ struct Engine {
             }
         }
         return launch_fold_stats(dstats, acc, nt, nt, err, n_stack, n_err, n, nt, C, s);
+    }
+    // DQMC::sweep_unequalTime (source/dqmc.cpp:458-515) with propagate_unequalTime_GF_forward :223-248, propagate_Bt0_Bbt :250-264,
+    // stabilize_unequalTime :266-285.  No Monte Carlo moves: B_l comes from the current fields (what the reference's B_ / invB_
+    // caches hold after sweep_beta_to_0), Gtt[0] is the current G, Bbt = stack[i + 1] as the backward sweep left it.
+    Mat utm(int which, int l) const { return Mat{utG[which] + (long)l * C * nn, nn}; }
+    int sweep_unequal() {
+        if (!utG[0]) {
+            for (int w = 0; w < 3; ++w) DQ_TRY(dalloc(&utG[w], (size_t)(nt + 1) * C * nn));
+            DQ_TRY(dalloc(&utTmp, (size_t)3 * C * nn)); DQ_TRY(dalloc(&utErr, (size_t)C * 3 * n_stack));
+            for (int b = 0; b < 2; ++b) { DQ_TRY(dalloc(&utL[b], C * nn)); DQ_TRY(dalloc(&utD[b], (size_t)C * n)); DQ_TRY(dalloc(&utR[b], C * nn)); DQ_TRY(dalloc(&utP[b], (size_t)C * n)); }
+        }
+        auto bt = [&](int b) { return LdrRef{Mat{utL[b], nn}, Vec{utD[b], (long)n}, Mat{utR[b], nn}, utP[b], &utTri[b]}; };
+        int cur = 0, n_err = 0;
+        DQ_TRY(launch_copy(mG(), utm(0, 0), nn, C, s));
+        for (int l = 0; l < nt; ++l) {
+            if (l == 0) {                                                                            // :234-239
+                DQ_TRY(launch_copy(utm(0, 0), utm(1, 0), nn, C, s));
+                DQ_TRY(launch_axpb_identity(utm(0, 0), utm(2, 0), 1.0, -1.0, n, C, s));
+            }
+            DQ_TRY(ctx.gemm(CMat(expK, nn), utm(0, l), ctx.T(0)));                                   // :240 Gtt = B Gtt B^-1
+            DQ_TRY(ctx.gemm(ctx.T(0), CMat(invexpK, nn), utm(0, l + 1), ev(l), CVec(), iev(l)));
+            DQ_TRY(ctx.gemm(CMat(expK, nn), utm(1, l), utm(1, l + 1), ev(l)));                       // :241 Gt0 = B Gt0
+            DQ_TRY(ctx.gemm(utm(2, l), CMat(invexpK, nn), utm(2, l + 1), CVec(), CVec(), iev(l)));   // :242 G0t = G0t B^-1
+            const int is = stack_idx(l);
+            if (local_l(l) == loc_l_end[is]) {
+                for (int w = 0; w < 3; ++w) DQ_TRY(launch_copy(utm(w, l + 1), Mat{utTmp + (long)w * C * nn, nn}, nn, C, s));
+                Mat bb; DQ_TRY(Bbar(is, &bb));
+                if (is == 0) DQ_TRY(ctx.to_ldr(bb, bt(cur)));                                        // :255-259
+                else { DQ_TRY(ctx.mat_mul_ldr(bb, bt(cur), bt(cur ^ 1))); cur ^= 1; }
+                if (l == nt - 1) {                                                                   // :267-276
+                    DQ_TRY(ctx.inv_I_plus_ldr(bt(cur), utm(0, l + 1), logdet));
+                    DQ_TRY(launch_axpb_identity(utm(0, l + 1), utm(1, l + 1), -1.0, 1.0, n, C, s));
+                    DQ_TRY(launch_axpb_identity(utm(0, l + 1), utm(2, l + 1), -1.0, 0.0, n, C, s));
+                } else {                                                                             // :278-282, Bbt = stack[is + 1]
+                    DQ_TRY(ctx.inv_I_plus_ldr_mul_ldr(bt(cur), stk(is + 1), utm(0, l + 1)));
+                    DQ_TRY(ctx.inv_invldr_plus_ldr(bt(cur), stk(is + 1), utm(1, l + 1), false));
+                    DQ_TRY(ctx.inv_invldr_plus_ldr(stk(is + 1), bt(cur), utm(2, l + 1), true));
+                }
+                for (int w = 0; w < 3; ++w) {                                                        // check_error x 3, :502-507
+                    DQ_TRY(launch_max_abs_diff(CMat(utTmp + (long)w * C * nn, nn), utm(w, l + 1), utErr + n_err, 3L * n_stack, n, C, s));
+                    ++n_err;
+                }
+            }
+        }
+        ut_valid = true;
+        return launch_fold_stats(dstats, acc, nt, 0, utErr, 3L * n_stack, n_err, n, nt, C, s);
     }
     int sync_and_check() {
         DQ_HIP(hipStreamSynchronize(s));
@@ -663,6 +727,19 @@ int dqmc_global_action(dqmc_engine* h, double* S) {
         }
         S[c] = -2.0 * ld[c] - (lb + lg);
     }
+    return 0;
+}
+int dqmc_sweep_unequal_time(dqmc_engine* h) {
+    CHECK_E(h); Engine& e = h->e; DQ_HIP(hipSetDevice(e.device));
+    if (!e.stack_valid) { set_error("sweep_unequal_time: call dqmc_init first"); return DQMC_EINVAL; }
+    return e.sweep_unequal();
+}
+int dqmc_get_G_tau(dqmc_engine* h, int which, int l, double* out) {
+    CHECK_E(h); Engine& e = h->e; DQ_HIP(hipSetDevice(e.device));
+    if (which < 0 || which > 2 || l < 0 || l > e.nt) { set_error("get_G_tau: which in 0..2, l in 0..nt"); return DQMC_ERANGE; }
+    if (!e.ut_valid) { set_error("get_G_tau: run dqmc_sweep_unequal_time first"); return DQMC_EINVAL; }
+    DQ_TRY(e.sync_and_check());
+    DQ_HIP(hipMemcpy(out, e.utG[which] + (long)l * e.C * e.nn, sizeof(double) * e.C * e.nn, hipMemcpyDeviceToHost));
     return 0;
 }
 int dqmc_measure_equal_time(dqmc_engine* h, int L1, int L2, double* scalars, double* chi_r) {

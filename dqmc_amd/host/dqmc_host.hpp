@@ -356,6 +356,7 @@ class DQMC {
     AttractiveHubbard& model_;
     dqmc_engine* e_ = nullptr;
     int nt_, n_stab_, n_stack_;
+    bool isUnequalTime_ = false;
     std::vector<int32_t> perm_; std::vector<uint8_t> kprop_; std::vector<double> u_;
     void draw_half_sweep(bool forward) {
         const int ns = model_.ns();
@@ -368,6 +369,7 @@ public:
     DQMC(const utility::parameters& params, AttractiveHubbard& model, int device = 0) : model_(model) {
         nt_ = params.getInt("simulation", "nt"); n_stab_ = params.getInt("simulation", "n_stab");
         n_stack_ = (int)std::ceil(static_cast<double>(nt_) / n_stab_);
+        try { isUnequalTime_ = params.getBool("simulation", "isMeasureUnequalTime"); } catch (...) { isUnequalTime_ = false; }   // source/dqmc.cpp:9
         const GHQField& f = model.fields();
         dqmc_detail::check(dqmc_create(&e_, device, model.ns(), nt_, n_stab_, model.g(), f.gamma_table().data(), f.eta_table().data(),
                                        model.expK(0).data(), model.invexpK(0).data()));
@@ -398,7 +400,15 @@ public:
     // source/dqmc.cpp:337-396 / :398-456; asynchronous, greens are refreshed by download()
     void sweep_0_to_beta(std::vector<GF>&, std::vector<LDRStack>&) { draw_half_sweep(true); dqmc_detail::check(dqmc_sweep_0_to_beta(e_, perm_.data(), kprop_.data(), u_.data())); }
     void sweep_beta_to_0(std::vector<GF>&, std::vector<LDRStack>&) { draw_half_sweep(false); dqmc_detail::check(dqmc_sweep_beta_to_0(e_, perm_.data(), kprop_.data(), u_.data())); }
-    void sweep_unequalTime(std::vector<GF>&, std::vector<LDRStack>&) {}          // out of scope; no-op as with isMeasureUnequalTime=false (source/dqmc.cpp:461-463)
+    // source/dqmc.cpp:458-515: a no-op unless [simulation] isMeasureUnequalTime = true (:461-463); the Gtt / Gt0 / G0t series stay in HBM,
+    // download_tau() fetches one slice (GF::Gtt[l], Gt0[l], G0t[l] of include/stackngf.h:15-29)
+    void sweep_unequalTime(std::vector<GF>&, std::vector<LDRStack>&) { if (isUnequalTime_) dqmc_detail::check(dqmc_sweep_unequal_time(e_)); }
+    enum Tau { Gtt = 0, Gt0 = 1, G0t = 2 };
+    std::vector<double> download_tau(Tau which, int l) {
+        std::vector<double> m((size_t)model_.ns() * model_.ns());
+        dqmc_detail::check(dqmc_get_G_tau(e_, (int)which, l, m.data())); return m;
+    }
+    bool isUnequalTime() const { return isUnequalTime_; }
     double global_action() { double S; dqmc_detail::check(dqmc_global_action(e_, &S)); return S; }   // source/model.cpp:140-159
     // ---- equal-time observables on the device (source/model.cpp:167-288, include/measurementh5.h:13-66) ----
     struct EqualTime { double density = 0, doubleOcc = 0, swave = 0; std::vector<double> densityCorr_r; long long n = 0; };

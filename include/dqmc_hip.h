@@ -209,6 +209,18 @@ int dqmc_measure_equal_time(dqmc_engine* e, int L1, int L2, double* scalars, dou
 int dqmc_measure_accumulate(dqmc_engine* e, int L1, int L2);
 int dqmc_measure_fetch(dqmc_engine* e, double* scalars_sum, double* chi_r_sum, int64_t* n_measurements, int reset);
 
+/* ---- unequal-time path ------------------------------------
+ * DQMC::sweep_unequalTime (source/dqmc.cpp:458-515; propagate_unequalTime_GF_forward
+ * :223-248, propagate_Bt0_Bbt :250-264, stabilize_unequalTime :266-285, with
+ * stablelinalg::inv_invldr_plus_ldr source/stablelinalg.cpp:160-190): from the current
+ * G = Gtt[0], fields and stacks (as sweep_beta_to_0 leaves them) builds Gtt[l],
+ * Gt0[l] = G(tau_l, 0), G0t[l] = G(0, tau_l) for l = 0..nt in HBM; the three wrap
+ * errors per stabilisation go into the same statistics as check_error.  Asynchronous. */
+int dqmc_sweep_unequal_time(dqmc_engine* e);
+/* GF::Gtt[l] / Gt0[l] / G0t[l] (include/stackngf.h:15-29): which = 0 / 1 / 2,
+ * l in 0..nt, out [n_chains][n*n] column-major.                                      */
+int dqmc_get_G_tau(dqmc_engine* e, int which, int l, double* out);
+
 /* Number of accepted proposals / kernel time (ms, HIP events on the engine's
  * stream) spent inside the local-update kernels since the last call -- the
  * live measurement bench.py uses for the rank-1 roofline.                    */

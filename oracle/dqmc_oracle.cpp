@@ -359,6 +359,23 @@ int inv_I_plus_ldr_mul_ldr(const LDR& F1, const LDR& F2, double* G) {
  * ------------------------------------------------------------------ */
 struct Stats { double acc_rate = 0, max_err = 0, sum_err = 0, n_err = 0; int64_t n_accepted = 0, n_proposed = 0; };
 
+/* stablelinalg::inv_invldr_plus_ldr, source/stablelinalg.cpp:160-190: G = [F1^-1 + F2]^-1 */
+int inv_invldr_plus_ldr(const LDR& F1, const LDR& F2, double* G) {
+    const int n = F1.n; vecd D1l, D1s, D2l, D2s; split_d(F1.d, D1l, D1s); split_d(F2.d, D2l, D2s);
+    vecd Dinv((size_t)n * n, 0.0); for (int i = 0; i < n; ++i) Dinv[i + (size_t)n * i] = 1.0 / D2l[i];
+    vecd X((size_t)n * n); int rc = solve(n, F2.R.data(), Dinv.data(), X.data()); if (rc) return rc;     /* :177-178 R2^-1 D2l^-1 */
+    vecd d1linv(n); for (int i = 0; i < n; ++i) d1linv[i] = 1.0 / D1l[i];
+    vecd T((size_t)n * n), TA((size_t)n * n), T2((size_t)n * n), TB((size_t)n * n);
+    gemm(n, F1.L.data(), true, X.data(), false, T.data()); diag_mul_mat(n, d1linv.data(), T.data(), TA.data());   /* :180 */
+    mat_mul_diag(n, F2.L.data(), D2s.data(), T.data()); gemm(n, F1.R.data(), false, T.data(), false, T2.data());
+    diag_mul_mat(n, D1s.data(), T2.data(), TB.data());                                                     /* :181 */
+    vecd M((size_t)n * n); for (size_t k = 0; k < (size_t)n * n; ++k) M[k] = TA[k] + TB[k];                /* :182 */
+    vecd RHS((size_t)n * n); diag_mul_mat(n, D1s.data(), F1.R.data(), RHS.data());                         /* :184 diag(D1s) R1 */
+    vecd Y((size_t)n * n); rc = solve(n, M.data(), RHS.data(), Y.data()); if (rc) return rc;             /* :186 */
+    gemm(n, X.data(), false, Y.data(), false, G);                                                         /* :188 */
+    return OK;
+}
+
 struct Engine {
     int n = 0, nt = 0, n_stab = 0, n_stack = 0;
     double g = 0, alpha = -1.0, gamma[4], eta[4];
@@ -473,6 +490,49 @@ struct Engine {
         }
         return OK;
     }
+    /* ---- unequal-time path ----------------------------------------------
+     * DQMC::sweep_unequalTime source/dqmc.cpp:458-515 with propagate_unequalTime_GF_forward :223-248,
+     * propagate_Bt0_Bbt :250-264, stabilize_unequalTime :266-285.  B_l / B_l^-1 are rebuilt from the
+     * current fields (the reference reads its B_ / invB_ caches, which sweep_beta_to_0 left in exactly
+     * that state); Gtt[0] is the current G.  Fills ut[0] = Gtt[0..nt], ut[1] = Gt0, ut[2] = G0t.     */
+    std::vector<vecd> ut[3];
+    int sweep_unequal() {
+        const size_t nn = (size_t)n * n;
+        for (int w = 0; w < 3; ++w) ut[w].assign(nt + 1, vecd());
+        ut[0][0] = G;
+        LDR Bt0, Bbt;
+        for (int l = 0; l < nt; ++l) {
+            if (l == 0) {                                                         /* :234-239 */
+                ut[1][0] = ut[0][0];
+                ut[2][0] = ut[0][0]; for (int i = 0; i < n; ++i) ut[2][0][i + (size_t)n * i] -= 1.0;
+            }
+            vecd b, ib, T(nn); B(l, b); invB(l, ib);
+            ut[0][l + 1].resize(nn); ut[1][l + 1].resize(nn); ut[2][l + 1].resize(nn);
+            gemm(n, b.data(), false, ut[0][l].data(), false, T.data()); gemm(n, T.data(), false, ib.data(), false, ut[0][l + 1].data());   /* :240 */
+            gemm(n, b.data(), false, ut[1][l].data(), false, ut[1][l + 1].data());                                                     /* :241 */
+            gemm(n, ut[2][l].data(), false, ib.data(), false, ut[2][l + 1].data());                                                    /* :242 */
+            const int is = stack_idx(l);
+            if (local_l(l) == loc_l_end[is]) {                                     /* :482-511 */
+                const vecd Gtt_tmp = ut[0][l + 1], Gt0_tmp = ut[1][l + 1], G0t_tmp = ut[2][l + 1];
+                vecd bb; Bbar(is, bb); int rc;
+                if (is == 0) rc = to_ldr(n, bb.data(), Bt0); else { LDR o; rc = mat_mul_ldr(bb.data(), Bt0, o); Bt0 = o; }                /* :255-259 */
+                if (rc) return rc;
+                if (is < n_stack - 1) Bbt = stack[is + 1];                           /* :261-263 */
+                if (l == nt - 1) {                                                   /* :267-276 */
+                    double ld = 0.0; rc = inv_I_plus_ldr(Bt0, ut[0][l + 1].data(), &ld); if (rc) return rc; logdet = ld;
+                    for (size_t k = 0; k < nn; ++k) { ut[1][l + 1][k] = -ut[0][l + 1][k]; ut[2][l + 1][k] = -ut[0][l + 1][k]; }
+                    for (int i = 0; i < n; ++i) ut[1][l + 1][i + (size_t)n * i] += 1.0;                    /* I - G */
+                } else {                                                             /* :278-282 */
+                    rc = inv_I_plus_ldr_mul_ldr(Bt0, Bbt, ut[0][l + 1].data()); if (rc) return rc;
+                    rc = inv_invldr_plus_ldr(Bt0, Bbt, ut[1][l + 1].data()); if (rc) return rc;
+                    rc = inv_invldr_plus_ldr(Bbt, Bt0, ut[2][l + 1].data()); if (rc) return rc;
+                    for (size_t k = 0; k < nn; ++k) ut[2][l + 1][k] = -ut[2][l + 1][k];
+                }
+                check_error(Gtt_tmp, ut[0][l + 1]); check_error(Gt0_tmp, ut[1][l + 1]); check_error(G0t_tmp, ut[2][l + 1]);   /* :502-507 */
+            }
+        }
+        return OK;
+    }
     /* AttractiveHubbard::global_action, source/model.cpp:140-159 (sums over
      * arma::imat memory order: column-major nt x nv, i.e. i outer, l inner) */
     double global_action() const {
@@ -583,10 +643,18 @@ int orc_wrap_backward(orc_engine* e, int l) { if (l < 0 || l >= e->nt) return fa
 int orc_local_update_slice(orc_engine* e, int l, const int32_t* perm, const uint8_t* kprop, const double* u, int* accepted) { if (l < 0 || l >= e->nt) return fail(ERANGE_, "slice"); int a = e->local_update(l, perm, kprop, u); if (accepted) *accepted = a; return OK; }
 int orc_calculate_Bbar(orc_engine* e, int is, double* out) { if (is < 0 || is >= e->n_stack) return fail(ERANGE_, "stack index"); vecd bb; e->Bbar(is, bb); std::copy(bb.begin(), bb.end(), out); return OK; }
 int orc_global_action(orc_engine* e, double* S) { *S = e->global_action(); return OK; }
+int orc_sweep_unequal_time(orc_engine* e) { int rc = e->sweep_unequal(); return rc ? fail(rc, "sweep_unequalTime failed") : OK; }
+int orc_get_G_tau(orc_engine* e, int which, int l, double* out) {
+    if (which < 0 || which > 2 || l < 0 || l > e->nt) return fail(ERANGE_, "get_G_tau: which in 0..2, l in 0..nt");
+    if (e->ut[which].empty() || e->ut[which][l].empty()) return fail(EINVAL_, "get_G_tau: run sweep_unequal_time first");
+    std::copy(e->ut[which][l].begin(), e->ut[which][l].end(), out); return OK;
+}
 int orc_measure_equal_time(orc_engine* e, int L1, int L2, double* scalars, double* chi_r) {
     if (L1 < 1 || L2 < 1 || L1 * L2 != e->n) return fail(EINVAL_, "measure_equal_time: L1*L2 must equal n_sites");
     double sc[3]; vecd chi((size_t)e->n); e->measure_equal_time(L1, L2, sc, chi.data());
-    if (scalars) std::copy(sc, sc + 3, scalars); if (chi_r) std::copy(chi.begin(), chi.end(), chi_r); return OK;
+    if (scalars) std::copy(sc, sc + 3, scalars);
+    if (chi_r) std::copy(chi.begin(), chi.end(), chi_r);
+    return OK;
 }
 int orc_measure_accumulate(orc_engine* e, int L1, int L2) {
     if (L1 < 1 || L2 < 1 || L1 * L2 != e->n) return fail(EINVAL_, "measure_accumulate: L1*L2 must equal n_sites");

@@ -189,3 +189,12 @@ def equal_time_observables(G, L1, L2):
     chi = np.zeros((L1, L2))
     np.add.at(chi, (dx, dy), ninj / n)
     return np.array([dens, docc, swave]), chi
+
+
+def inv_invldr_plus_ldr(F1, F2):          # source/stablelinalg.cpp:160-190: [F1^-1 + F2]^-1
+    (L1, d1, R1), (L2, d2, R2) = F1, F2
+    D1l, D1s = _split(d1); D2l, D2s = _split(d2)
+    X = np.linalg.solve(R2, np.diag(1.0 / D2l))
+    M = (1.0 / D1l)[:, None] * (L1.T @ X) + D1s[:, None] * (R1 @ (L2 * D2s[None, :]))
+    Y = np.linalg.solve(M, D1s[:, None] * R1)
+    return X @ Y

@@ -430,6 +430,38 @@ def test_observables_batched_and_golden(hip):
         assert max(np.abs(sc - sc2).max(), np.abs(chi - chi2).max()) < float(z["tol"]) * 10 * scale, name
 
 
+# ---- unequal-time path on the device -------------------------------------------------------
+@pytest.mark.parametrize("cfg,tol", [("cfg1", 1e-10), ("cfg2", 1e-10), ("cfg3", 1e-9)])
+def test_unequal_time_parity(hip, orc, cfg, tol):
+    """Gtt[l], Gt0[l], G0t[l] for every slice after one sweep on both sides, device vs oracle (fp64; cfg 3 is held to 1e-9 of the
+    largest entry: 200 slices of propagation between 20 stabilisations), plus the three wrap errors per stabilisation in the stats."""
+    m = HubbardModel(**CONFIGS[cfg]); rng = np.random.default_rng(6)
+    f0 = m.random_fields(17); sf, sb = m.random_stream(rng), m.random_stream(rng)
+    e = m.engine(hip); o = m.engine(orc)
+    for x in (e, o):
+        x.set_fields(f0); x.init(); x.sweep_0_to_beta(*sf); x.sweep_beta_to_0(*sb); x.sweep_unequal_time()
+    worst = 0.0
+    for which in ("tt", "t0", "0t"):
+        for l in (range(m.nt + 1) if m.nt <= 80 else list(range(0, m.nt + 1, 7)) + [m.nt - 1, m.nt]):
+            a, b = e.get_G_tau(which, l), o.get_G_tau(which, l)
+            worst = max(worst, np.abs(a - b).max() / max(1.0, np.abs(b).max()))
+    print(f"{cfg}: unequal-time max rel err {worst:.2e}")
+    assert worst < tol
+    se, so = e.stats(), o.stats()
+    # the wrap errors themselves are rounding noise of the propagation (1e-9 .. 1e-5): same count, same order of magnitude
+    assert se.n_err == so.n_err and se.max_err < 1e-6 + 100 * so.max_err and so.max_err < 1e-6 + 100 * se.max_err
+    assert abs(e.get_logdet() - o.get_logdet()) < 1e-9 * abs(o.get_logdet())
+    G0 = e.get_G()
+    assert np.abs(e.get_G_tau("tt", m.nt) - G0).max() < 1e-6 and np.abs(e.get_G_tau("tt", 0) - G0).max() == 0
+    from dqmc_amd import DqmcError
+    with pytest.raises(DqmcError) as ei:
+        e.get_G_tau("tt", m.nt + 1)
+    assert ei.value.code == -4
+    e2 = m.engine(hip); e2.set_fields(f0); e2.init()
+    with pytest.raises(DqmcError):
+        e2.get_G_tau("tt", 0)                  # before any sweep_unequal_time
+
+
 def test_error_codes(hip):
     from dqmc_amd import DqmcError
     m = HubbardModel(**CONFIGS["cfg1"]); e = m.engine(hip); e.set_fields(m.random_fields(1))
