@@ -48,7 +48,7 @@ ABI_SYMBOLS = [
     "wrap_forward", "wrap_backward", "local_update_slice", "calculate_Bbar", "global_action",
     "update_kernel_time", "set_profiling",
     "measure_equal_time", "measure_accumulate", "measure_fetch",
-    "sweep_unequal_time", "get_G_tau",
+    "sweep_unequal_time", "get_G_tau", "measure_unequal_time", "measure_unequal_fetch",
 ]
 
 
@@ -104,6 +104,8 @@ class DqmcLib:
         if self.has_symbol("sweep_unequal_time"):
             g("sweep_unequal_time").argtypes = [C.c_void_p]
             g("get_G_tau").argtypes = [C.c_void_p, C.c_int, C.c_int, c_double_p]
+            g("measure_unequal_time").argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, c_double_p]
+            g("measure_unequal_fetch").argtypes = [C.c_void_p, c_double_p, c_int64_p, C.c_int]
         g("to_ldr").argtypes = [C.c_int] + [c_double_p] * 4
         g("ldr_mul_mat").argtypes = [C.c_int] + [c_double_p] * 7
         g("mat_mul_ldr").argtypes = [C.c_int] + [c_double_p] * 7
@@ -338,6 +340,22 @@ class Engine:
     def get_G_tau(self, which: str, l: int) -> np.ndarray:
         """which in {"tt", "t0", "0t"}: Gtt[l], Gt0[l] = G(tau_l, 0), G0t[l] = G(0, tau_l) of the last sweep_unequal_time."""
         B = np.empty(self.C * self.n * self.n); self._c("get_G_tau", {"tt": 0, "t0": 1, "0t": 2}[which], int(l), _p(B)); return self._mats_out(B)
+
+    def _ut_cube(self, flat, L1, L2):
+        a = flat.reshape(self.C, 3, self.nt + 1, L2, L1).transpose(0, 1, 2, 4, 3)      # [chain][obs][tau][dx_idx][dy_idx]
+        return a if self.batched else a[0]
+
+    def measure_unequal_time(self, L1: int, L2: int, accumulate: bool = False):
+        """greenTau, doublonTau, currxxTau [3][nt + 1][L1][L2] of the last sweep_unequal_time (or, accumulate=True, add them to the bin)."""
+        if accumulate:
+            self._c("measure_unequal_time", int(L1), int(L2), 1, None); return None
+        out = np.empty(self.C * 3 * (self.nt + 1) * L1 * L2)
+        self._c("measure_unequal_time", int(L1), int(L2), 0, _p(out)); return self._ut_cube(out, L1, L2)
+
+    def measure_unequal_fetch(self, L1: int, L2: int, reset: bool = True):
+        out = np.empty(self.C * 3 * (self.nt + 1) * L1 * L2); cnt = np.zeros(1, dtype=np.int64)
+        self._c("measure_unequal_fetch", _p(out), cnt.ctypes.data_as(c_int64_p), 1 if reset else 0)
+        return self._ut_cube(out, L1, L2), int(cnt[0])
 
     def set_profiling(self, on: bool):
         self._c("set_profiling", int(bool(on)))

@@ -70,6 +70,10 @@ int launch_split_d(CVec d, Vec dl_inv, Vec ds, double* logsum, int n, int n_chai
 // equal-time observables of G (source/model.cpp:167-288) in displacement space (include/measurementh5.h:13-66):
 // out[chain][0..2] = density, doubleOcc, swave; out[chain][3 + dx_idx + L1*dy_idx] = chi_r.  accumulate: out += (else out =)
 int launch_measure_equal_time(CMat G, double* out, long out_stride, int L1, int L2, int accumulate, int n_chains, hipStream_t s);
+// dynamical observables (source/model.cpp:290-394) of the series Gtt / Gt0 / G0t [nt + 1][chains][n*n] in displacement space:
+// out[chain][obs][tau][bin], obs = greenTau, doublonTau, currxxTau.  accumulate: out += (else out =)
+int launch_measure_unequal_time(const double* Gtt, const double* Gt0, const double* G0t, double* out, long out_stride, int L1, int L2, int nt,
+                                int accumulate, int n_chains, hipStream_t s);
 // out = a * in + b * I (n x n)
 int launch_axpb_identity(CMat in, Mat out, double a, double b, int n, int n_chains, hipStream_t s);
 // out = in (n*n)

@@ -264,4 +264,57 @@ int launch_axpb_identity(CMat in, Mat out, double a, double b, int n, int n_chai
     return 0;
 }
 
+
+// ---- dynamical observables -----------------------------------------------------------------------
+// grid = (nt + 1 slices, chains), thread t <-> displacement bin t; per slice tau, with G00 = Gtt[0], spin up == spin down:
+//   greenTau(i,j)   = 2 Gt0(i,j)                                              source/model.cpp:290-314
+//   doublonTau(i,j) = Gt0(i,j)^2                                              :316-345
+//   currxxTau(i,j)  = -(t1 - t2 - t3 + t4), ix = i + x, jx = j + x            :347-394
+//       t1 = [2 Gtt(ix,i)][2 G00(jx,j)] - 2 G0t(jx,i) Gt0(ix,j)     t2 = [2 Gtt(ix,i)][2 G00(j,jx)] - 2 G0t(j,i) Gt0(ix,jx)
+//       t3 = [2 Gtt(i,ix)][2 G00(jx,j)] - 2 G0t(jx,ix) Gt0(i,j)     t4 = [2 Gtt(i,ix)][2 G00(j,jx)] - 2 G0t(j,ix) Gt0(i,jx)
+//   chi_r(d, tau) = (1/N) sum_i chi(i, i + d, tau)                            include/measurementh5.h:20-66
+__global__ __launch_bounds__(1024) void measure_unequal_time_kernel(const double* Gtt_p, const double* Gt0_p, const double* G0t_p, double* out_p,
+                                                                    long out_stride, int L1, int L2, int nt, int accumulate, int n_chains) {
+    const int tau = blockIdx.x, chain = blockIdx.y;
+    const int n = L1 * L2;
+    const long nn = (long)n * n;
+    const double* __restrict__ Gtt = Gtt_p + ((long)tau * n_chains + chain) * nn;
+    const double* __restrict__ Gt0 = Gt0_p + ((long)tau * n_chains + chain) * nn;
+    const double* __restrict__ G0t = G0t_p + ((long)tau * n_chains + chain) * nn;
+    const double* __restrict__ G00 = Gtt_p + (long)chain * nn;
+    double* out = out_p + (long)chain * out_stride;
+    const int t = threadIdx.x;
+    if (t >= n) return;
+    const int dx = (t % L1) - (L1 / 2 - 1), dy = (t / L1) - (L2 / 2 - 1);
+    double sg = 0.0, sd = 0.0, sc = 0.0;
+#define AT(M, r, c) M[(r) + (long)n * (c)]
+    for (int i = 0; i < n; ++i) {
+        const int xi = i % L1, yi = i / L1;
+        const int xj = ((xi + dx) % L1 + L1) % L1, yj = ((yi + dy) % L2 + L2) % L2;
+        const int j = yj * L1 + xj;
+        const int ix = yi * L1 + (xi + 1) % L1, jx = yj * L1 + (xj + 1) % L1;          // Lattice::site_neighbors(., {1,0}, 0), include/lattice.h:100-107
+        const double g = AT(Gt0, i, j);
+        sg += g + g; sd += g * g;
+        const double dc1i = 2.0 * AT(Gtt, ix, i), dc2i = 2.0 * AT(Gtt, i, ix);
+        const double dc1j = 2.0 * AT(G00, jx, j), dc2j = 2.0 * AT(G00, j, jx);
+        const double c1 = 2.0 * AT(G0t, jx, i) * AT(Gt0, ix, j), c2 = 2.0 * AT(G0t, j, i) * AT(Gt0, ix, jx);
+        const double c3 = 2.0 * AT(G0t, jx, ix) * g, c4 = 2.0 * AT(G0t, j, ix) * AT(Gt0, i, jx);
+        sc += -((dc1i * dc1j - c1) - (dc1i * dc2j - c2) - (dc2i * dc1j - c3) + (dc2i * dc2j - c4));
+    }
+#undef AT
+    const long slab = (long)(nt + 1) * n;
+    double* o = out + (long)tau * n + t;
+    if (accumulate) { o[0] += sg / n; o[slab] += sd / n; o[2 * slab] += sc / n; }
+    else { o[0] = sg / n; o[slab] = sd / n; o[2 * slab] = sc / n; }
+}
+int launch_measure_unequal_time(const double* Gtt, const double* Gt0, const double* G0t, double* out, long out_stride, int L1, int L2, int nt,
+                                int accumulate, int n_chains, hipStream_t s) {
+    const int n = L1 * L2;
+    if (n < 1 || n > 1024) { set_error("measure_unequal_time: L1*L2 must be in 1..1024"); return -1; }
+    const int threads = ((n + 63) / 64) * 64;
+    hipLaunchKernelGGL(measure_unequal_time_kernel, dim3(nt + 1, n_chains), dim3(threads), 0, s, Gtt, Gt0, G0t, out, out_stride, L1, L2, nt, accumulate, n_chains);
+    DQ_HIP(hipGetLastError());
+    return 0;
+}
+
 }  // namespace dq

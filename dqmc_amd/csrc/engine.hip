@@ -203,6 +203,7 @@ struct Engine {
     double* utG[3] = {nullptr, nullptr, nullptr}; double* utTmp = nullptr; double* utErr = nullptr;
     double* utL[2] = {nullptr, nullptr}; double* utD[2] = {nullptr, nullptr}; double* utR[2] = {nullptr, nullptr}; int* utP[2] = {nullptr, nullptr};
     bool utTri[2] = {false, false}; bool ut_valid = false;
+    double* utMeasNow = nullptr; double* utMeasSum = nullptr; long long ut_meas_count = 0;     // [C][3][nt + 1][n] dynamical observables: last / bin sums
     long long meas_count = 0;                                    // measurements accumulated in meas_sum
     char* slice_sync = nullptr;                                  // [C][64 B] hand-off words of the persistent slice kernel
     int* acc = nullptr;                                          // [C][nt]
@@ -230,7 +231,7 @@ struct Engine {
         if (s) (void)hipStreamSynchronize(s);
         for (auto& p : ev_pairs) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
         if (stage_free) (void)hipEventDestroy(stage_free);
-        void* ptrs[] = {utG[0], utG[1], utG[2], utTmp, utErr, utL[0], utL[1], utD[0], utD[1], utR[0], utR[1], utP[0], utP[1], meas_now, meas_sum, GT, slice_sync, prep, stackP, expK, invexpK, fields, expv, invexpv, tabs, tab8, G, Gtmp, bb0, bb1, stackL, stackD, stackR, tmpL, tmpD, tmpR,
+        void* ptrs[] = {utMeasNow, utMeasSum, utG[0], utG[1], utG[2], utTmp, utErr, utL[0], utL[1], utD[0], utD[1], utR[0], utR[1], utP[0], utP[1], meas_now, meas_sum, GT, slice_sync, prep, stackP, expK, invexpK, fields, expv, invexpv, tabs, tab8, G, Gtmp, bb0, bb1, stackL, stackD, stackR, tmpL, tmpD, tmpR,
                         logdet, rs_perm, rs_k, rs_u, Upanel, Wpanel, state, acc, err, dstats, r1scratch};
         for (void* p : ptrs) if (p) (void)hipFree(p);
         if (h_stage) (void)hipHostFree(h_stage);
@@ -408,6 +409,8 @@ struct Engine {
         if (!utG[0]) {
             for (int w = 0; w < 3; ++w) DQ_TRY(dalloc(&utG[w], (size_t)(nt + 1) * C * nn));
             DQ_TRY(dalloc(&utTmp, (size_t)3 * C * nn)); DQ_TRY(dalloc(&utErr, (size_t)C * 3 * n_stack));
+            const size_t mcount = (size_t)C * 3 * (nt + 1) * n;
+            DQ_TRY(dalloc(&utMeasNow, mcount)); DQ_TRY(dalloc(&utMeasSum, mcount)); DQ_HIP(hipMemsetAsync(utMeasSum, 0, sizeof(double) * mcount, s));
             for (int b = 0; b < 2; ++b) { DQ_TRY(dalloc(&utL[b], C * nn)); DQ_TRY(dalloc(&utD[b], (size_t)C * n)); DQ_TRY(dalloc(&utR[b], C * nn)); DQ_TRY(dalloc(&utP[b], (size_t)C * n)); }
         }
         auto bt = [&](int b) { return LdrRef{Mat{utL[b], nn}, Vec{utD[b], (long)n}, Mat{utR[b], nn}, utP[b], &utTri[b]}; };
@@ -740,6 +743,30 @@ int dqmc_get_G_tau(dqmc_engine* h, int which, int l, double* out) {
     if (!e.ut_valid) { set_error("get_G_tau: run dqmc_sweep_unequal_time first"); return DQMC_EINVAL; }
     DQ_TRY(e.sync_and_check());
     DQ_HIP(hipMemcpy(out, e.utG[which] + (long)l * e.C * e.nn, sizeof(double) * e.C * e.nn, hipMemcpyDeviceToHost));
+    return 0;
+}
+int dqmc_measure_unequal_time(dqmc_engine* h, int L1, int L2, int accumulate, double* out) {
+    CHECK_E(h); Engine& e = h->e; DQ_HIP(hipSetDevice(e.device));
+    if (L1 < 1 || L2 < 1 || L1 * L2 != e.n) { set_error("measure_unequal_time: L1*L2 must equal n_sites"); return DQMC_EINVAL; }
+    if (!e.ut_valid) { set_error("measure_unequal_time: run dqmc_sweep_unequal_time first"); return DQMC_EINVAL; }
+    const long stride = 3L * (e.nt + 1) * e.n;
+    if (accumulate) {
+        DQ_TRY(launch_measure_unequal_time(e.utG[0], e.utG[1], e.utG[2], e.utMeasSum, stride, L1, L2, e.nt, 1, e.C, e.s));
+        ++e.ut_meas_count; return 0;
+    }
+    if (!out) { set_error("measure_unequal_time: out is NULL"); return DQMC_EINVAL; }
+    DQ_TRY(launch_measure_unequal_time(e.utG[0], e.utG[1], e.utG[2], e.utMeasNow, stride, L1, L2, e.nt, 0, e.C, e.s));
+    DQ_TRY(e.sync_and_check());
+    DQ_HIP(hipMemcpy(out, e.utMeasNow, sizeof(double) * e.C * stride, hipMemcpyDeviceToHost));
+    return 0;
+}
+int dqmc_measure_unequal_fetch(dqmc_engine* h, double* out_sum, int64_t* n_measurements, int reset) {
+    CHECK_E(h); Engine& e = h->e; DQ_HIP(hipSetDevice(e.device)); DQ_TRY(e.sync_and_check());
+    if (!e.utMeasSum) { set_error("measure_unequal_fetch: nothing measured yet"); return DQMC_EINVAL; }
+    const size_t cnt = (size_t)e.C * 3 * (e.nt + 1) * e.n;
+    if (out_sum) DQ_HIP(hipMemcpy(out_sum, e.utMeasSum, sizeof(double) * cnt, hipMemcpyDeviceToHost));
+    if (n_measurements) *n_measurements = e.ut_meas_count;
+    if (reset) { DQ_HIP(hipMemset(e.utMeasSum, 0, sizeof(double) * cnt)); e.ut_meas_count = 0; }
     return 0;
 }
 int dqmc_measure_equal_time(dqmc_engine* h, int L1, int L2, double* scalars, double* chi_r) {

@@ -409,6 +409,20 @@ public:
         dqmc_detail::check(dqmc_get_G_tau(e_, (int)which, l, m.data())); return m;
     }
     bool isUnequalTime() const { return isUnequalTime_; }
+    // greenTau / doublonTau / currxxTau (source/model.cpp:290-394) of the last sweep_unequalTime in displacement space:
+    // [3][nt + 1][L1*L2]; measure_unequal() adds them to the device-side bin, fetch_unequal_bin() returns the bin averages
+    std::vector<double> measure_unequal_time(const Lattice& lat) {
+        std::vector<double> out((size_t)3 * (nt_ + 1) * lat.L1() * lat.L2());
+        dqmc_detail::check(dqmc_measure_unequal_time(e_, lat.L1(), lat.L2(), 0, out.data())); return out;
+    }
+    void measure_unequal(const Lattice& lat) { if (isUnequalTime_) dqmc_detail::check(dqmc_measure_unequal_time(e_, lat.L1(), lat.L2(), 1, nullptr)); }
+    std::vector<double> fetch_unequal_bin(const Lattice& lat, long long* n_out = nullptr) {
+        std::vector<double> out((size_t)3 * (nt_ + 1) * lat.L1() * lat.L2()); int64_t cnt = 0;
+        dqmc_detail::check(dqmc_measure_unequal_fetch(e_, out.data(), &cnt, 1));
+        if (cnt > 0) for (double& x : out) x /= (double)cnt;
+        if (n_out) *n_out = cnt;
+        return out;
+    }
     double global_action() { double S; dqmc_detail::check(dqmc_global_action(e_, &S)); return S; }   // source/model.cpp:140-159
     // ---- equal-time observables on the device (source/model.cpp:167-288, include/measurementh5.h:13-66) ----
     struct EqualTime { double density = 0, doubleOcc = 0, swave = 0; std::vector<double> densityCorr_r; long long n = 0; };

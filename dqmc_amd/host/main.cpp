@@ -50,11 +50,18 @@ int main(int argc, char** argv) {
             sim.sweep_beta_to_0(greens, propagation_stacks);
             sim.sweep_unequalTime(greens, propagation_stacks);
             sim.measure(lat);                                          // measurements.measure(greens, lat), source/main.cpp:165 -- on the device, asynchronous
+            sim.measure_unequal(lat);                                  // the dynamical observables of the same call, when isMeasureUnequalTime
             if (isweep % n_sweeps == 0) {                              // measurements.accumulate(lat), :167-169: one bin done
                 const DQMC::EqualTime bin = sim.fetch_bin(lat);
                 std::cout << "bin " << isweep / n_sweeps << " (" << bin.n << " sweeps): density " << std::setprecision(8) << bin.density
                           << "  doubleOcc " << bin.doubleOcc << "  swave " << bin.swave << "  densityCorr(r=0) "
                           << bin.densityCorr_r[(size_t)(lat.L1() / 2 - 1) + (size_t)lat.L1() * (lat.L2() / 2 - 1)] << '\n';
+                if (sim.isUnequalTime()) {
+                    long long nu = 0; const std::vector<double> ut = sim.fetch_unequal_bin(lat, &nu);
+                    const size_t r0 = (size_t)(lat.L1() / 2 - 1) + (size_t)lat.L1() * (lat.L2() / 2 - 1), nb = (size_t)lat.L1() * lat.L2();
+                    const int nt_ = params.getInt("simulation", "nt");
+                    std::cout << "      greenTau(r=0; tau = 0, beta/2, beta) " << ut[r0] << " " << ut[(size_t)(nt_ / 2) * nb + r0] << " " << ut[(size_t)nt_ * nb + r0] << '\n';
+                }
             }
         }
         sim.download(greens[0]);

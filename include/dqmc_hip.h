@@ -221,6 +221,17 @@ int dqmc_sweep_unequal_time(dqmc_engine* e);
  * l in 0..nt, out [n_chains][n*n] column-major.                                      */
 int dqmc_get_G_tau(dqmc_engine* e, int which, int l, double* out);
 
+/* Dynamical observables of the last dqmc_sweep_unequal_time in displacement space:
+ * Observables::calculate_greenTau / calculate_doublonTau / calculate_currxxTau
+ * (source/model.cpp:290-394) reduced per time slice as transform::chi_site_to_chi_r
+ * does (include/measurementh5.h:20-66, n_orb = 1).
+ *   out [n_chains][3][nt + 1][L1*L2]: observable (greenTau, doublonTau, currxxTau),
+ *   slice tau, element (dx_idx, dy_idx) at dx_idx + L1*dy_idx.
+ * accumulate = 0: evaluate and return (out may not be NULL); accumulate = 1: add to the
+ * device-side bin sums instead (out ignored); fetch returns sums and count.           */
+int dqmc_measure_unequal_time(dqmc_engine* e, int L1, int L2, int accumulate, double* out);
+int dqmc_measure_unequal_fetch(dqmc_engine* e, double* out_sum, int64_t* n_measurements, int reset);
+
 /* Number of accepted proposals / kernel time (ms, HIP events on the engine's
  * stream) spent inside the local-update kernels since the last call -- the
  * live measurement bench.py uses for the rank-1 roofline.                    */

@@ -533,6 +533,46 @@ struct Engine {
         }
         return OK;
     }
+    /* Observables::calculate_greenTau :290-314, calculate_doublonTau :316-345, calculate_currxxTau :347-394 (source/model.cpp)
+     * on the series of sweep_unequal, each slice reduced by transform::chi_site_to_chi_r (include/measurementh5.h:20-66).
+     * out [3][nt + 1][L1*L2]                                                                                              */
+    vecd ut_meas_sum; long long ut_meas_count = 0;
+    void measure_unequal(int L1, int L2, double* out) const {
+        const size_t nn = (size_t)n * n; const size_t slab = (size_t)(nt + 1) * n;
+        std::fill(out, out + 3 * slab, 0.0);
+        auto site_neighbor_x = [&](int idx) { const int ux = idx % L1, uy = idx / L1; return uy * L1 + ((ux + 1) % L1 + L1) % L1; };   /* lattice.h:100-107 */
+        const vecd& G00 = ut[0][0];
+        vecd chi[3]; for (auto& c : chi) c.resize(nn);
+        for (int tau = 0; tau <= nt; ++tau) {
+            const vecd &Gtt = ut[0][tau], &Gt0 = ut[1][tau], &G0t = ut[2][tau];
+            auto at = [&](const vecd& M, int r, int c) { return M[r + (size_t)n * c]; };
+            for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) {
+                chi[0][i + (size_t)n * j] = at(Gt0, i, j) + at(Gt0, i, j);                        /* Gt0up + Gt0dn */
+                chi[1][i + (size_t)n * j] = at(Gt0, i, j) * at(Gt0, i, j);
+            }
+            for (int i = 0; i < n; ++i) {
+                const int ix = site_neighbor_x(i);
+                const double dc1i = at(Gtt, ix, i) + at(Gtt, ix, i), dc2i = at(Gtt, i, ix) + at(Gtt, i, ix);
+                for (int j = 0; j < n; ++j) {
+                    const int jx = site_neighbor_x(j);
+                    const double dc1j = at(G00, jx, j) + at(G00, jx, j), dc2j = at(G00, j, jx) + at(G00, j, jx);
+                    const double c1 = at(G0t, jx, i) * at(Gt0, ix, j) + at(G0t, jx, i) * at(Gt0, ix, j);
+                    const double c2 = at(G0t, j, i) * at(Gt0, ix, jx) + at(G0t, j, i) * at(Gt0, ix, jx);
+                    const double c3 = at(G0t, jx, ix) * at(Gt0, i, j) + at(G0t, jx, ix) * at(Gt0, i, j);
+                    const double c4 = at(G0t, j, ix) * at(Gt0, i, jx) + at(G0t, j, ix) * at(Gt0, i, jx);
+                    const double t1 = dc1i * dc1j - c1, t2 = dc1i * dc2j - c2, t3 = dc2i * dc1j - c3, t4 = dc2i * dc2j - c4;
+                    chi[2][i + (size_t)n * j] = -(t1 - t2 - t3 + t4);
+                }
+            }
+            for (int ob = 0; ob < 3; ++ob)
+                for (int ij = 0; ij < n * n; ++ij) {                                             /* measurementh5.h:36-62 */
+                    const int i = ij % n, j = ij / n;
+                    const int cxi = i % L1, cyi = i / L1, cxj = j % L1, cyj = j / L1;
+                    const int dxi = pbc_shortest(cxj - cxi, L1) + L1 / 2 - 1, dyi = pbc_shortest(cyj - cyi, L2) + L2 / 2 - 1;
+                    out[ob * slab + (size_t)tau * n + dxi + (size_t)L1 * dyi] += chi[ob][i + (size_t)n * j] / n;
+                }
+        }
+    }
     /* AttractiveHubbard::global_action, source/model.cpp:140-159 (sums over
      * arma::imat memory order: column-major nt x nv, i.e. i outer, l inner) */
     double global_action() const {
@@ -648,6 +688,26 @@ int orc_get_G_tau(orc_engine* e, int which, int l, double* out) {
     if (which < 0 || which > 2 || l < 0 || l > e->nt) return fail(ERANGE_, "get_G_tau: which in 0..2, l in 0..nt");
     if (e->ut[which].empty() || e->ut[which][l].empty()) return fail(EINVAL_, "get_G_tau: run sweep_unequal_time first");
     std::copy(e->ut[which][l].begin(), e->ut[which][l].end(), out); return OK;
+}
+int orc_measure_unequal_time(orc_engine* e, int L1, int L2, int accumulate, double* out) {
+    if (L1 < 1 || L2 < 1 || L1 * L2 != e->n) return fail(EINVAL_, "measure_unequal_time: L1*L2 must equal n_sites");
+    if (e->ut[0].empty()) return fail(EINVAL_, "measure_unequal_time: run sweep_unequal_time first");
+    const size_t cnt = (size_t)3 * (e->nt + 1) * e->n;
+    if (accumulate) {
+        vecd tmp(cnt); e->measure_unequal(L1, L2, tmp.data());
+        if (e->ut_meas_sum.empty()) e->ut_meas_sum.assign(cnt, 0.0);
+        for (size_t k = 0; k < cnt; ++k) e->ut_meas_sum[k] += tmp[k];
+        ++e->ut_meas_count; return OK;
+    }
+    if (!out) return fail(EINVAL_, "measure_unequal_time: out is NULL");
+    e->measure_unequal(L1, L2, out); return OK;
+}
+int orc_measure_unequal_fetch(orc_engine* e, double* out_sum, int64_t* n_meas, int reset) {
+    if (e->ut_meas_sum.empty()) return fail(EINVAL_, "measure_unequal_fetch: nothing measured yet");
+    if (out_sum) std::copy(e->ut_meas_sum.begin(), e->ut_meas_sum.end(), out_sum);
+    if (n_meas) *n_meas = e->ut_meas_count;
+    if (reset) { std::fill(e->ut_meas_sum.begin(), e->ut_meas_sum.end(), 0.0); e->ut_meas_count = 0; }
+    return OK;
 }
 int orc_measure_equal_time(orc_engine* e, int L1, int L2, double* scalars, double* chi_r) {
     if (L1 < 1 || L2 < 1 || L1 * L2 != e->n) return fail(EINVAL_, "measure_equal_time: L1*L2 must equal n_sites");

@@ -198,3 +198,33 @@ def inv_invldr_plus_ldr(F1, F2):          # source/stablelinalg.cpp:160-190: [F1
     M = (1.0 / D1l)[:, None] * (L1.T @ X) + D1s[:, None] * (R1 @ (L2 * D2s[None, :]))
     Y = np.linalg.solve(M, D1s[:, None] * R1)
     return X @ Y
+
+
+def unequal_time_observables(Gtt, Gt0, G0t, L1, L2):
+    """Vectorised numpy evaluation of greenTau / doublonTau / currxxTau (source/model.cpp:290-394) in displacement space
+    (include/measurementh5.h:20-66).  Gtt, Gt0, G0t: arrays [nt + 1][n][n].  Returns [3][nt + 1][L1][L2]."""
+    Gtt, Gt0, G0t = (np.asarray(a, dtype=np.float64) for a in (Gtt, Gt0, G0t))
+    ntau, n, _ = Gtt.shape
+    idx = np.arange(n); x = idx % L1; y = idx // L1
+    nbx = y * L1 + (x + 1) % L1                                   # site_neighbors(i, {1,0}, 0)
+    def pbc(d, L):
+        d = np.where(d > L // 2, d - L, d); return np.where(d <= -(L // 2), d + L, d)
+    dx = pbc(x[None, :] - x[:, None], L1) + L1 // 2 - 1; dy = pbc(y[None, :] - y[:, None], L2) + L2 // 2 - 1
+    G00 = Gtt[0]
+    out = np.zeros((3, ntau, L1, L2))
+    dc1j = 2.0 * G00[nbx, idx]; dc2j = 2.0 * G00[idx, nbx]            # [j]
+    for tau in range(ntau):
+        A, T0, Z = Gtt[tau], Gt0[tau], G0t[tau]
+        green = 2.0 * T0; doublon = T0 * T0
+        dc1i = 2.0 * A[nbx, idx]; dc2i = 2.0 * A[idx, nbx]              # [i]
+        # c_k[i, j]
+        c1 = 2.0 * Z[nbx][:, idx].T * T0[nbx][:, idx]                    # G0t(jx,i) Gt0(ix,j)
+        c2 = 2.0 * Z.T * T0[nbx][:, nbx]                                 # G0t(j,i) Gt0(ix,jx)
+        c3 = 2.0 * Z[nbx][:, nbx].T * T0                                 # G0t(jx,ix) Gt0(i,j)
+        c4 = 2.0 * Z[:, nbx].T * T0[:, nbx]                              # G0t(j,ix) Gt0(i,jx)
+        t1 = dc1i[:, None] * dc1j[None, :] - c1; t2 = dc1i[:, None] * dc2j[None, :] - c2
+        t3 = dc2i[:, None] * dc1j[None, :] - c3; t4 = dc2i[:, None] * dc2j[None, :] - c4
+        curr = -(t1 - t2 - t3 + t4)
+        for ob, M in enumerate((green, doublon, curr)):
+            np.add.at(out[ob, tau], (dx, dy), M / n)
+    return out

@@ -462,6 +462,28 @@ def test_unequal_time_parity(hip, orc, cfg, tol):
         e2.get_G_tau("tt", 0)                  # before any sweep_unequal_time
 
 
+@pytest.mark.parametrize("shape", [(4, 4, 4.0, 2.0, 20), (6, 4, 4.0, 3.0, 30), (16, 16, 8.0, 8.0, 200)])
+def test_dynamical_observables_parity(hip, orc, shape):
+    """greenTau / doublonTau / currxxTau cubes of the device against the oracle after sweep + sweep_unequal_time on both sides."""
+    L1, L2, U, beta, nt = shape
+    m = HubbardModel(L1=L1, L2=L2, U=U, beta=beta, nt=nt, n_stab=10); rng = np.random.default_rng(11)
+    f0 = m.random_fields(3); sf, sb = m.random_stream(rng), m.random_stream(rng)
+    e = m.engine(hip); o = m.engine(orc)
+    for x in (e, o):
+        x.set_fields(f0); x.init(); x.sweep_0_to_beta(*sf); x.sweep_beta_to_0(*sb); x.sweep_unequal_time()
+    a, b = e.measure_unequal_time(L1, L2), o.measure_unequal_time(L1, L2)
+    scale = max(1.0, np.abs(b).max()); err = np.abs(a - b).max()
+    print(f"{L1}x{L2}: dynamical observables max err {err:.2e} (scale {scale:.2e})")
+    assert a.shape == (3, nt + 1, L1, L2) and err < 1e-9 * scale
+    e.measure_unequal_time(L1, L2, accumulate=True); e.measure_unequal_time(L1, L2, accumulate=True)
+    tot, cnt = e.measure_unequal_fetch(L1, L2)
+    assert cnt == 2 and np.abs(tot - 2 * a).max() < 1e-12 * scale and e.measure_unequal_fetch(L1, L2)[1] == 0
+    from dqmc_amd import DqmcError
+    e2 = m.engine(hip); e2.set_fields(f0); e2.init()
+    with pytest.raises(DqmcError):
+        e2.measure_unequal_time(L1, L2)             # no unequal-time sweep yet
+
+
 def test_error_codes(hip):
     from dqmc_amd import DqmcError
     m = HubbardModel(**CONFIGS["cfg1"]); e = m.engine(hip); e.set_fields(m.random_fields(1))

@@ -212,3 +212,21 @@ def test_unequal_time_oracle(orc, cfg):
     from dqmc_amd import DqmcError
     with pytest.raises(DqmcError):
         e.get_G_tau("tt", m.nt + 1)
+
+
+def test_dynamical_observables_vs_numpy(orc):
+    """greenTau / doublonTau / currxxTau (source/model.cpp:290-394) per slice in displacement space: the oracle's loops against the
+    vectorised numpy evaluation on a non-square lattice; bin accumulation."""
+    L1, L2 = 6, 4
+    m = HubbardModel(L1=L1, L2=L2, U=4.0, beta=2.0, nt=20, n_stab=10); rng = np.random.default_rng(1)
+    e = m.engine(orc); e.set_fields(m.random_fields(5)); e.init()
+    e.sweep_0_to_beta(*m.random_stream(rng)); e.sweep_beta_to_0(*m.random_stream(rng)); e.sweep_unequal_time()
+    cube = e.measure_unequal_time(L1, L2)
+    G = [np.stack([e.get_G_tau(w, l) for l in range(m.nt + 1)]) for w in ("tt", "t0", "0t")]
+    ref = nr.unequal_time_observables(G[0], G[1], G[2], L1, L2)
+    assert cube.shape == (3, m.nt + 1, L1, L2) and np.abs(cube - ref).max() < 1e-13 * max(1.0, np.abs(ref).max())
+    # tau = 0: greenTau(r) = 2 G(0,0) averaged over translations
+    assert abs(cube[0, 0, L1 // 2 - 1, L2 // 2 - 1] - 2.0 * np.trace(G[0][0]) / m.n) < 1e-13
+    e.measure_unequal_time(L1, L2, accumulate=True); e.measure_unequal_time(L1, L2, accumulate=True)
+    tot, cnt = e.measure_unequal_fetch(L1, L2)
+    assert cnt == 2 and np.abs(tot - 2 * cube).max() < 1e-12 and e.measure_unequal_fetch(L1, L2)[1] == 0
