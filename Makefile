@@ -11,6 +11,10 @@ all: dqmc_amd/libdqmc_hip.so dqmc_amd/libdqmc_host.so dqmc_amd/dqmc_driver oracl
 $(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/wave.h include/dqmc_hip.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
+$(CSRC)/qr_colown.o: $(CSRC)/qr_colown_regs.inc
+$(CSRC)/qr_colown_regs.inc: scripts/gen_qr_colown_regs.py
+	python3 scripts/gen_qr_colown_regs.py
+
 dqmc_amd/libdqmc_hip.so: $(OBJS)
 	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ $(OBJS)
 

@@ -3,23 +3,21 @@
 // Green's-function update (AttractiveHubbard::local_update_ratio /
 // update_greens_local, source/model.cpp:90-138).
 //
-// Structure (one workgroup per Markov chain; blockIdx.y = chain, thread j <-> site j)
-//   scan kernel : walks the pre-drawn site order.  The acceptance ratio needs
-//                 only G_ii, which is kept in an LDS copy of the diagonal, so a
-//                 rejected proposal costs one LDS read and a handful of fp64
-//                 ops, evaluated redundantly by every lane (wave-uniform
-//                 control flow, no broadcast).  An accepted flip is NOT
-//                 applied to G in HBM; it is appended to an LDS-resident
-//                 low-rank correction  G_eff = G + sum_m U_m W_m^T  (the
-//                 "delayed update" the reference README lists as future work,
-//                 README.md:41):  u = G_eff[:,i], w = G_eff[i,:] - e_i are
-//                 formed with one dot-product sweep over the <= KD pairs, and
-//                 the LDS diagonal is advanced by pref*u_j*w_j.  The Markov
-//                 chain is the reference's; only the rounding order of the
-//                 rank-1 sums differs.
-//   flush kernel: whole chip, fp64 MFMA:  G += U^T-panel x W-panel  (N x k x N).
-// A slice is ceil(N/KD) (scan, flush) pairs; pairs past the end of the walk
-// find pos == N / k == 0 and exit immediately.
+// The acceptance ratio needs only G_ii, which is kept in an LDS copy of the diagonal.  An accepted flip is NOT applied
+// to G in HBM; it is appended to a low-rank correction  G_eff = G + sum_m U_m W_m^T  (the "delayed update" the
+// reference README lists as future work, README.md:41):  u = G_eff[:,i], w = G_eff[i,:] - e_i are formed with one pass
+// over the <= KD pending pairs, and the diagonal is advanced by pref*u_j*w_j.  After KD = 32 flips (a "window") the
+// correction is flushed into G with fp64 MFMAs:  G += U^T-panel x W-panel  (N x k x N).  The Markov chain is the
+// reference's; only the rounding order of the rank-1 sums differs.
+//
+// Kernels (blockIdx.y = chain, thread j <-> site j):
+//   slice_kernel        n <= 256, few chains: the whole slice in ONE launch -- workgroup 0 walks (walk_window), the other
+//                       (n/32)^2 workgroups each own a tile of G and of its transposed copy GT and flush every window;
+//                       hand-offs through one tagged word and one arrival counter, see the comment at the kernel.
+//   scan_kernel<256> +  the same walk / flush code as separate launches, ceil(N/KD) pairs per slice (pairs past the end of
+//   flush_kernel<true>  the walk find pos == N / k == 0 and exit); used when the single-launch grid would not be co-resident.
+//   scan_kernel<1024> + n > 256: the pending pairs live in LDS (scan_group), G rows are read directly (no GT).
+//   flush_kernel<false>
 #include "common.h"
 #include <cstdlib>
 #include "wave.h"
