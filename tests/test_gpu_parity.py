@@ -484,6 +484,19 @@ def test_dynamical_observables_parity(hip, orc, shape):
         e2.measure_unequal_time(L1, L2)             # no unequal-time sweep yet
 
 
+def test_bitwise_reproducible_at_full_size(hip):
+    """Same inputs, two engines: G, fields, log det and the stabilisation errors agree BITWISE after a full cfg-3 sweep (no atomics in
+    any reduction, fixed flush / split-K summation orders, hand-offs that publish complete windows only)."""
+    m = HubbardModel(**CONFIGS["cfg3"]); rng = np.random.default_rng(31)
+    f0 = m.random_fields(9); sf, sb = m.random_stream(rng), m.random_stream(rng)
+    res = []
+    for _ in range(2):
+        e = m.engine(hip); e.set_fields(f0); e.init(); e.sweep_0_to_beta(*sf); e.sweep_beta_to_0(*sb)
+        st = e.stats(); res.append((e.get_G(), e.get_fields(), e.get_logdet(), st.max_err, st.n_accepted))
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    assert res[0][2] == res[1][2] and res[0][3] == res[1][3] and res[0][4] == res[1][4]
+
+
 def test_error_codes(hip):
     from dqmc_amd import DqmcError
     m = HubbardModel(**CONFIGS["cfg1"]); e = m.engine(hip); e.set_fields(m.random_fields(1))
