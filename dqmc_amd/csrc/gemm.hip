@@ -153,14 +153,22 @@ __global__ __launch_bounds__(256) void gemm_tile64_kernel(GemmDesc g, int tiles_
     constexpr int LDT = 80;
     __shared__ double As[2][16][LDT];
     __shared__ double Bs[2][16][LDT];
-    const int chain = blockIdx.y;
+    // XCD-aware tile mapping.  Workgroups are dealt to the 8 XCDs round-robin in dispatch order and every XCD has its own L2:
+    // with (tile, chain) = (blockIdx.x, blockIdx.y) the 16 tiles of one chain land on all 8 XCDs and each L2 pulls that chain's
+    // A and B panels from the fabric separately -- 512 MB per 128-chain GEMM, which is what bounded the kernel at 105 us.
+    // Here workgroup w serves logical slot (w % 8) * (total / 8) + w / 8, so a chain's tiles share one XCD and one L2.
+    const int tiles2 = tiles_per_dim * tiles_per_dim;
+    const int total = tiles2 * (int)gridDim.y;
+    int lin = (int)blockIdx.x + tiles2 * (int)blockIdx.y;
+    if ((total & 7) == 0) lin = (lin & 7) * (total >> 3) + (lin >> 3);
+    const int chain = lin / tiles2, tile = lin % tiles2;
     const int n = g.n;
     const double* __restrict__ A = g.A.at(chain);
     const double* __restrict__ B = g.B.at(chain);
     double* __restrict__ C = g.C.at(chain);
     const double* __restrict__ ks = g.ks.p ? g.ks.at(chain) : nullptr;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int i0 = (blockIdx.x % tiles_per_dim) * 64, j0 = (blockIdx.x / tiles_per_dim) * 64;
+    const int i0 = (tile % tiles_per_dim) * 64, j0 = (tile / tiles_per_dim) * 64;
     const int r = lane & 15, kk = lane >> 4;
     const int wi = (wave & 1) * 32, wj = (wave >> 1) * 32;
     // staging roles

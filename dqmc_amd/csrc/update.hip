@@ -262,7 +262,7 @@ __device__ __forceinline__ double vec_get16(d16v v, int q) { return v[q]; }
 // Proposals are handled in groups of 8 with three register sets used round-robin (the group loop is unrolled by 3 so
 // that every set is addressed statically): while group g is walked, the G column / row elements of groups g + 1 and
 // g + 2 are in flight, and nothing but those loads is outstanding, so the wait before a group is a partial vmcnt.
-template <bool COH>
+template <bool COH, bool PANELS = true>     // PANELS: write the window's U / W rows to memory for flush workgroups / kernels (the solo kernel flushes from LDS)
 __device__ __forceinline__ int walk_window(const ScanShared& sh, int& pos, double dg, int n, int kd, int j, bool live, const double* __restrict__ G,
                                            const double* __restrict__ GT, const UpdateDesc& d, long slice_off, int chain, int8_t* fields_g,
                                            double* __restrict__ Up, double* __restrict__ Wp PROF_ARG) {
@@ -365,7 +365,7 @@ __device__ __forceinline__ int walk_window(const ScanShared& sh, int& pos, doubl
     unsigned long long td0; STAMP(td0)
 #endif
     // ---- window end: the flush's operands and the accepted field changes leave the workgroup (coalesced, from registers) ----
-    if (live) {
+    if (PANELS && live) {
 #define DQ_DUMP(OU, OW, M, BASE)                                                                       \
         if (COH) { st_coh(Up + (BASE + M) * n + j, OU[M]); st_coh(Wp + (BASE + M) * n + j, OW[M]); }   \
         else { Up[(BASE + M) * n + j] = OU[M]; Wp[(BASE + M) * n + j] = OW[M]; }
@@ -670,6 +670,107 @@ __global__ __launch_bounds__(256) void slice_kernel(UpdateDesc d, SliceSync* syn
     }
 }
 
+// ---- solo slice kernel: one workgroup per chain does the walk AND its own flushes --------------------------------------
+// For engines with many chains the single-launch kernel above cannot be used (its 1 + (n/32)^2 workgroups per chain must all
+// be resident), and the scan / flush kernel pairs cost 2 x ceil(N/KD) launches per slice with every chain waiting for the
+// slowest one twice per window.  Here a chain needs nobody else: after each window its workgroup applies G += U^T W and
+// GT += W^T U itself, the MFMA operands taken straight from the LDS pair store (no panel round trip through memory), 64
+// 16x16 sub-tiles per wave.  A flush costs ~27 us on one CU (fp64 MFMA bound) instead of a ~5 us hand-off, which is the wrong
+// trade for ONE chain and the right one once there are as many chains as CUs: every CU works on its own chain and the slice is
+// one launch (measured break-even between 128 and 256 chains, see launch_update_slice).
+// NB sub-tiles at a time: all their G / GT loads are issued before the first MFMA (a sub-tile alone is one L2 round trip per 1024 MFMA
+// clocks).  Plain loads and stores: only this workgroup touches the chain during the launch, and workgroup-scope synchronisation
+// (barrier) is all its waves need to see each other's stores through the CU's own L1.
+template <int NB>
+__device__ __forceinline__ void flush_tiles_lds(double* __restrict__ G, double* __restrict__ GT, const double2* __restrict__ UW, int st0, int st_step,
+                                                int n_st, int tiles16, int n, int k, int lane) {
+    const int r = lane & 15, kk = lane >> 4;
+    double gv[NB][4], gt[NB][4];
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+        const int st = min(st0 + q * st_step, n_st - 1);
+        const int a0 = (st % tiles16) * 16, b0 = (st / tiles16) * 16;
+        const int a = min(a0 + r, n - 1), b = min(b0 + r, n - 1);
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int bb = min(b0 + kk + 4 * reg, n - 1), aa = min(a0 + kk + 4 * reg, n - 1);
+            gv[q][reg] = G[a + (long)n * bb]; gt[q][reg] = GT[b + (long)n * aa];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+        const int st = st0 + q * st_step;
+        if (st >= n_st) break;                                        // wave-uniform
+        const int a0 = (st % tiles16) * 16, b0 = (st / tiles16) * 16;
+        const int a = min(a0 + r, n - 1), b = min(b0 + r, n - 1);
+        const bool a_ok = a0 + r < n, b_ok = b0 + r < n;
+        d4 acc = {0.0, 0.0, 0.0, 0.0}, acc_t = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < UPDATE_KD / 4; ++s) {
+            if (4 * s >= k) break;                                    // wave-uniform
+            const int m = 4 * s + kk;
+            const bool ok = m < k;
+            const int mc = min(m, k - 1);
+            const double um = (ok && a_ok) ? UW[mc * n + a].x : 0.0, wm = (ok && b_ok) ? UW[mc * n + b].y : 0.0;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wm, um, acc, 0, 0, 0);                 // rows <-> b, cols <-> a
+            acc_t = __builtin_amdgcn_mfma_f64_16x16x4f64(um, wm, acc_t, 0, 0, 0);             // rows <-> a, cols <-> b
+        }
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int bb = b0 + kk + 4 * reg, aa = a0 + kk + 4 * reg;
+            if (a_ok && bb < n) G[a + (long)n * bb] = gv[q][reg] + acc[reg];
+            if (b_ok && aa < n) GT[b + (long)n * aa] = gt[q][reg] + acc_t[reg];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void slice_solo_kernel(UpdateDesc d, int l, int acc_slot, int kd) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int chain = blockIdx.y;
+    const int n = d.n;
+    double* __restrict__ G = d.G.at(chain);
+    double* __restrict__ GT = d.GT.at(chain);
+    const int j = threadIdx.x, lane = j & 63, wave = j >> 6;
+    const bool live = j < n;
+    ScanShared sh;
+    scan_shared_init(sh, smem, n, kd, true);
+    const double* tab_g = reinterpret_cast<const double*>(d.tabs + chain);
+    const long slice_off = (long)l * n;
+    int8_t* fields_g = d.fields + (long)chain * d.f_stride + slice_off;
+    double dg = 0.0;
+    if (live) {
+        const long off = (long)chain * d.rs_stride + slice_off + j;
+        const int i = d.perm[off];
+        const int kp = d.kprop[off];
+        const int old_f = fields_g[i];
+        sh.site[j] = i; sh.newf[j] = (signed char)c_proposal[old_f][kp];
+        sh.rbv[j] = tab_g[old_f * 3 + kp]; sh.dlt[j] = tab_g[12 + old_f * 3 + kp]; sh.ur[j] = d.u[off];
+        dg = G[j + (long)n * j];
+        sh.diag[j] = dg;
+    }
+    if (j < 32) sh.tl[j] = tab_g[j];
+    __syncthreads();
+    int pos = 0, total_acc = 0;
+    const int tiles16 = (n + 15) / 16;
+#ifdef DQ_SCAN_STAMPS
+    ScanProf prof;
+#endif
+    for (;;) {
+        const int k = walk_window<false, false>(sh, pos, dg, n, kd, j, live, G, GT, d, slice_off, chain, fields_g, nullptr, nullptr PROF_PASS);
+        total_acc += k;
+        __syncthreads();                                              // every pair of the window is in LDS
+        if (k > 0) {
+            const int n_st = tiles16 * tiles16;                       // 16x16 sub-tiles of G (and their mirrors in GT): wave w takes w, w + 4, ...
+            for (int st = wave; st < n_st; st += 4 * 8) flush_tiles_lds<8>(G, GT, sh.UW, st, 4, n_st, tiles16, n, k, lane);
+        }
+        if (pos >= n) break;
+        __syncthreads();                                              // fence + barrier: the flushed tiles are visible to every wave of this workgroup
+        if (live) { dg = G[j + (long)n * j]; sh.diag[j] = dg; }
+        __syncthreads();
+    }
+    if (j == 0) d.acc_out[(long)chain * d.acc_stride + acc_slot] = total_acc;
+}
+
 static int pick_kd(int n) {
     // LDS budget: 16*kd*n + n*(5*8+4+1) + tables <= ~150 KiB
     const long budget = 150 * 1024 - (long)n * 48 - 1024;
@@ -703,6 +804,17 @@ int launch_update_slice(const UpdateDesc& d, int l, int acc_slot, int n_chains, 
     if (!multi_kernel && regs && d.slice_sync && (long)(1 + tiles * tiles) * n_chains <= 224) {
         hipLaunchKernelGGL(slice_kernel, dim3(1 + tiles * tiles, n_chains), dim3(256), lds, s, d, reinterpret_cast<SliceSync*>(d.slice_sync), l, acc_slot, kd,
                            tiles, d.info);
+        DQ_HIP(hipGetLastError());
+        return 0;
+    }
+    static const bool pairs = getenv("DQMC_SLICE_PAIRS") != nullptr;                   // A/B switch: scan / flush kernel pairs
+    // measured (cfg 3, sweeps/s, solo vs pairs): 64 chains 166 / 214, 128 chains 251 / 275, 256 chains 324 / 307 -- a chain's own CU
+    // flushes slower than the whole chip does, so the solo kernel pays once there are enough chains to occupy every CU
+    static const bool solo_forced = getenv("DQMC_SLICE_SOLO") != nullptr;
+    if (regs && !pairs && !multi_kernel && (n_chains >= 224 || solo_forced)) {
+        static bool solo_attr = false;
+        if (!solo_attr) { DQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(slice_solo_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); solo_attr = true; }
+        hipLaunchKernelGGL(slice_solo_kernel, dim3(1, n_chains), dim3(256), lds, s, d, l, acc_slot, kd);
         DQ_HIP(hipGetLastError());
         return 0;
     }

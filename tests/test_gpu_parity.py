@@ -361,8 +361,13 @@ def test_alternative_kernel_paths_in_subprocess(hip):
             "for l in range(3):\n"
             "    e.wrap_forward(l); acc.append(int(e.local_update_slice(l, *m.random_stream(rng, 1))))\n"
             "G2 = e.get_G(); f = e.get_fields()\n"
+            "eb = m.engine(dqmc_amd.lib(), n_chains=4); eb.set_fields(np.stack([m.random_fields(40 + c) for c in range(4)])); eb.init(); accb = []\n"
+            "for l in range(2):\n"
+            "    eb.wrap_forward(l); st = [m.random_stream(rng, 1) for _ in range(4)]\n"
+            "    accb += [int(a) for a in eb.local_update_slice(l, *(np.stack([x[q] for x in st]) for q in range(3)))]\n"
+            "Gb = eb.get_G()\n"
             "print(json.dumps({'ld': e.get_logdet(), 'g00': float(G[0, 0]), 'sum': float(np.abs(G).sum()), 'acc': acc, "
-            "'sum2': float(np.abs(G2).sum()), 'fsum': int((f[:3] * np.arange(1, f.shape[1] + 1)).sum())}))") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+            "'sum2': float(np.abs(G2).sum()), 'fsum': int((f[:3] * np.arange(1, f.shape[1] + 1)).sum()), 'accb': accb, 'sumb': float(np.abs(Gb).sum())}))") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     def run(env_extra):
         env = dict(os.environ); env.update(env_extra)
         out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
@@ -370,13 +375,15 @@ def test_alternative_kernel_paths_in_subprocess(hip):
         return json.loads(out.stdout.strip().splitlines()[-1])
     ref = run({})
     for env in ({"DQMC_QR_COOP": "1"}, {"DQMC_QR_BLOCKCYCLIC": "1"}, {"DQMC_QR_STREAMING": "1"}, {"DQMC_LU_STREAMING": "1"}, {"DQMC_GEMM_V1": "1"},
-                {"DQMC_SLICE_MULTIKERNEL": "1"}):
+                {"DQMC_SLICE_MULTIKERNEL": "1"}, {"DQMC_SLICE_SOLO": "1"}):
         got = run(env)
         assert abs(got["ld"] - ref["ld"]) < 1e-8 * abs(ref["ld"]), (env, got, ref)
         assert abs(got["sum"] - ref["sum"]) < 1e-7 * abs(ref["sum"]), (env, got, ref)
         # three slices of wrap + local update (single-launch slice kernel vs scan / flush pairs, every factorisation variant)
         assert got["acc"] == ref["acc"] and got["fsum"] == ref["fsum"], (env, got, ref)
         assert abs(got["sum2"] - ref["sum2"]) < 1e-7 * abs(ref["sum2"]), (env, got, ref)
+        # four chains in one engine: scan / flush pairs by default, the solo slice kernel (walk + own flush per chain) under DQMC_SLICE_SOLO
+        assert got["accb"] == ref["accb"] and abs(got["sumb"] - ref["sumb"]) < 1e-7 * abs(ref["sumb"]), (env, got, ref)
 
 
 # ---- equal-time observables on the device ------------------------------------------------------
@@ -482,6 +489,26 @@ def test_dynamical_observables_parity(hip, orc, shape):
     e2 = m.engine(hip); e2.set_fields(f0); e2.init()
     with pytest.raises(DqmcError):
         e2.measure_unequal_time(L1, L2)             # no unequal-time sweep yet
+
+
+def test_batched_engine_matches_single_chain_engines(hip):
+    """Four cfg-3 chains in one engine (scan / flush kernel pairs; the solo kernel when DQMC_SLICE_SOLO is set or there are >= 224
+    chains -- exercised in the subprocess test below) against four single-chain engines (single-launch slice kernel): same accepted
+    flips and fields, G to 1e-9 of its largest entry (the flushes sum in a different order)."""
+    m = HubbardModel(**CONFIGS["cfg3"]); rng = np.random.default_rng(77)
+    C = 4
+    fs = np.stack([m.random_fields(300 + c) for c in range(C)])
+    per_f = [m.random_stream(rng) for _ in range(C)]; per_b = [m.random_stream(rng) for _ in range(C)]
+    sf = tuple(np.stack([x[q] for x in per_f]) for q in range(3)); sb = tuple(np.stack([x[q] for x in per_b]) for q in range(3))
+    eb = m.engine(hip, n_chains=C); eb.set_fields(fs); eb.init()
+    eb.sweep_0_to_beta(*sf); eb.sweep_beta_to_0(*sb)
+    Gb, fb, stb = eb.get_G(), eb.get_fields(), eb.stats()
+    for c in range(C):
+        e1 = m.engine(hip); e1.set_fields(fs[c]); e1.init()
+        e1.sweep_0_to_beta(sf[0][c], sf[1][c], sf[2][c]); e1.sweep_beta_to_0(sb[0][c], sb[1][c], sb[2][c])
+        G1 = e1.get_G()
+        assert np.array_equal(fb[c], e1.get_fields()) and stb[c].n_accepted == e1.stats().n_accepted
+        assert np.abs(Gb[c] - G1).max() < 1e-9 * max(1.0, np.abs(G1).max())
 
 
 def test_bitwise_reproducible_at_full_size(hip):
