@@ -119,15 +119,20 @@ __global__ __launch_bounds__(1024) void lu_kernel(Mat Am, int* perm_p, long perm
 //         upper-triangular R1; source/stablelinalg.cpp:51-52); X = R^-1 diag(dg) = Pi R1^-1 diag(dg)
 //         by back substitution only -- the permuted triangular solve that replaces the LU behind
 //         arma::solve(X, R, diagmat) at source/stablelinalg.cpp:112,147.
-template <int NR>
+#ifndef DQ_LU_SOLVE_PD
+#define DQ_LU_SOLVE_PD 4      // factor columns in flight per wave: a step costs ~0.15 us of instructions, an L2 round trip ~1 us
+#endif
+// CW = right-hand-side columns per wave.  The substitution is a chain of n dependent steps whose cost is instructions per step: a
+// single engine uses CW = 1 (4x the workgroups, the shortest step; measured -3 ms per cfg-3 sweep against CW = 4), engines with many
+// chains keep CW = 4 (fewer factor-column fetches per right-hand side).
+template <int NR, int CW>
 __global__ __launch_bounds__(256) void lu_solve_kernel(CMat LUm, const int* perm_p, long perm_stride, Mat Xm, CVec dg, int mode, int n) {
-    constexpr int CW = 4;
     const int chain = blockIdx.y;
     const double* __restrict__ LU = LUm.at(chain);
     const int* __restrict__ perm = perm_p + (long)chain * perm_stride;
     double* __restrict__ X = Xm.at(chain);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c0 = blockIdx.x * 16 + wave * CW;
+    const int c0 = (blockIdx.x * 4 + wave) * CW;
     if (c0 >= n) return;
     double x[CW][NR]; int prow[NR];
 #pragma unroll
@@ -152,7 +157,7 @@ __global__ __launch_bounds__(256) void lu_solve_kernel(CMat LUm, const int* perm
     // v_readlane (k is wave-uniform; a ds_bpermute shuffle costs ~10x more) and the factor columns of
     // the next FOUR steps are already in flight (they do not depend on x): a one-deep prefetch left
     // every step waiting on L2.  The ring of four is unrolled by hand so its slots are static registers.
-    constexpr int PD = 4;
+    constexpr int PD = DQ_LU_SOLVE_PD;
     // forward substitution, unit lower L
     if (!tri) {
         double lq[PD][NR];
@@ -161,7 +166,8 @@ __global__ __launch_bounds__(256) void lu_solve_kernel(CMat LUm, const int* perm
 #pragma unroll
             for (int k2 = 0; k2 < NR; ++k2) { const int r = lane + 64 * k2; const double v = LU[prow[k2] + cb]; lq[slot][k2] = (r > k && r < n) ? v : 0.0; }
         };
-        fetchL(0, 0); fetchL(1, 1); fetchL(2, 2); fetchL(3, 3);
+#pragma unroll
+        for (int e = 0; e < PD; ++e) fetchL(e, e);
 #pragma unroll
         for (int q = 0; q < NR; ++q) {
             for (int kb = 0; kb < 64; kb += PD) {
@@ -198,10 +204,11 @@ __global__ __launch_bounds__(256) void lu_solve_kernel(CMat LUm, const int* perm
         };
         // steps run k = ktop .. 0 with ktop = 64*NR - 1 rounded so that slot e serves k == e' (mod 4) statically
         const int ktop = 64 * NR - 1;
-        fetchU(3, ktop); fetchU(2, ktop - 1); fetchU(1, ktop - 2); fetchU(0, ktop - 3);
+#pragma unroll
+        for (int e = PD - 1; e >= 0; --e) fetchU(e, ktop - (PD - 1 - e));
 #pragma unroll
         for (int q = NR - 1; q >= 0; --q) {
-            for (int kb = 60; kb >= 0; kb -= PD) {
+            for (int kb = 64 - PD; kb >= 0; kb -= PD) {
 #pragma unroll
                 for (int e = PD - 1; e >= 0; --e) {
                     const int k = 64 * q + kb + e;
@@ -256,7 +263,8 @@ int launch_lu(Mat A, int* perm, long perm_stride, double* logabsdet, int accumul
 
 template <int NR>
 static int launch_solve_nr(CMat LU, const int* perm, long ps, Mat X, CVec dg, int mode, int n, int n_chains, hipStream_t s) {
-    hipLaunchKernelGGL((lu_solve_kernel<NR>), dim3((n + 15) / 16, n_chains), dim3(256), 0, s, LU, perm, ps, X, dg, mode, n);
+    if (n_chains <= 4) hipLaunchKernelGGL((lu_solve_kernel<NR, 1>), dim3((n + 3) / 4, n_chains), dim3(256), 0, s, LU, perm, ps, X, dg, mode, n);
+    else hipLaunchKernelGGL((lu_solve_kernel<NR, 4>), dim3((n + 15) / 16, n_chains), dim3(256), 0, s, LU, perm, ps, X, dg, mode, n);
     DQ_HIP(hipGetLastError());
     return 0;
 }
