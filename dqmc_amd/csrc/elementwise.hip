@@ -108,24 +108,34 @@ int launch_transpose_scale(CMat in, Mat out, CVec rs, int n, int n_chains, hipSt
     return 0;
 }
 
-// single block per chain: max |A - B|
-__global__ void max_abs_diff_kernel(CMat A, CMat B, double* err, long err_stride, int n) {
+// max |A - B| per chain (NaN propagates).  Sixteen workgroups per chain stream the two matrices (one workgroup is bound by what a single
+// CU pulls through its L1: 22 us for 1 MiB); wave maxima by DPP, block maxima folded with a 64-bit integer atomic max -- for
+// non-negative doubles (and NaN) the IEEE bit pattern orders like the value, so the result does not depend on arrival order.
+// The caller zeroes the err[] slots (one stream-ordered memset per half sweep) before the launches that target them.
+__global__ __launch_bounds__(256) void max_abs_diff_kernel(CMat A, CMat B, double* err, long err_stride, int n) {
     const int c = blockIdx.y;
-    const double* a = A.at(c); const double* b = B.at(c);
+    const double* __restrict__ a = A.at(c); const double* __restrict__ b = B.at(c);
     const long total = (long)n * n;
-    double m = 0.0;
-    for (long k = threadIdx.x; k < total; k += blockDim.x) { const double d = fabs(a[k] - b[k]); m = (d > m || d != d) ? d : m; }
-    __shared__ double red[1024];
-    red[threadIdx.x] = m;
-    __syncthreads();
-    for (int o = blockDim.x / 2; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) { const double x = red[threadIdx.x + o]; if (x > red[threadIdx.x] || x != x) red[threadIdx.x] = x; }
-        __syncthreads();
+    unsigned long long m = 0ULL;
+    for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < total; k += (long)gridDim.x * blockDim.x) {
+        const unsigned long long d = (unsigned long long)__double_as_longlong(fabs(a[k] - b[k]));      // |x| clears the sign bit: NaN stays the largest
+        m = d > m ? d : m;
     }
-    if (threadIdx.x == 0) err[(long)c * err_stride] = red[0];
+    m = wave_max_u64(m);
+    __shared__ unsigned long long red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long r = red[0];
+        for (int q = 1; q < 4; ++q) r = red[q] > r ? red[q] : r;
+        atomicMax(reinterpret_cast<unsigned long long*>(err + (long)c * err_stride), r);
+    }
 }
 int launch_max_abs_diff(CMat A, CMat B, double* err, long err_stride, int n, int n_chains, hipStream_t s) {
-    hipLaunchKernelGGL(max_abs_diff_kernel, dim3(1, n_chains), dim3(1024), 0, s, A, B, err, err_stride, n);
+    const long total = (long)n * n;
+    const long want = (total + 4095) / 4096;                                  // 16 elements per thread
+    const int blocks = (int)(want < 1 ? 1 : (want > 16 ? 16 : want));
+    hipLaunchKernelGGL(max_abs_diff_kernel, dim3(blocks, n_chains), dim3(256), 0, s, A, B, err, err_stride, n);
     DQ_HIP(hipGetLastError());
     return 0;
 }

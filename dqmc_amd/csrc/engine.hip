@@ -362,6 +362,7 @@ struct Engine {
     // DQMC::sweep_0_to_beta (source/dqmc.cpp:337-396)
     int sweep_fwd() {
         int n_err = 0;
+        DQ_HIP(hipMemsetAsync(err, 0, sizeof(double) * C * n_stack, s));             // max_abs_diff folds into zeroed slots
         for (int l = 0; l < nt; ++l) {
             DQ_TRY(wrap_forward(l));
             DQ_TRY(local_update(l));
@@ -383,6 +384,7 @@ struct Engine {
     // DQMC::sweep_beta_to_0 (source/dqmc.cpp:398-456)
     int sweep_bwd() {
         int n_err = 0;
+        DQ_HIP(hipMemsetAsync(err, 0, sizeof(double) * C * n_stack, s));
         for (int l = nt - 1; l >= 0; --l) {
             DQ_TRY(local_update(l));
             DQ_TRY(wrap_backward(l));
@@ -415,6 +417,7 @@ struct Engine {
         }
         auto bt = [&](int b) { return LdrRef{Mat{utL[b], nn}, Vec{utD[b], (long)n}, Mat{utR[b], nn}, utP[b], &utTri[b]}; };
         int cur = 0, n_err = 0;
+        DQ_HIP(hipMemsetAsync(utErr, 0, sizeof(double) * C * 3 * n_stack, s));
         DQ_TRY(launch_copy(mG(), utm(0, 0), nn, C, s));
         for (int l = 0; l < nt; ++l) {
             if (l == 0) {                                                                            // :234-239
