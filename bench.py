@@ -137,12 +137,12 @@ def main():
             "config": {"workload": f"{args.config}: {model.L1}x{model.L2} Hubbard U={model.U} beta={model.beta} Ltau={model.nt} n_stab={model.n_stab} t=1 mu=-0.1",
                        "chains_per_gpu": C, "n_chains_total": world * C, "parallelism": f"independent chains, {world} gpu x {C} chain"},
             "acceptance": acc_rate, "max_wrap_err": s1.max_err, "mean_wrap_err": s1.mean_err,
-            "roofline": {"kernel": "local update of one time slice (slice_kernel: walk + flush roles, + the G->GT transpose)", "bound": "hbm",
+            "roofline": {"kernel": "local update of one time slice (slice_kernel: walk + flush roles)", "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          # HBM-side bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, KB;
-                         # one slice_kernel + one transpose dispatch per slice, ~150 accepted flips in the probed slices;
-                         # profiles/r01_pmc_fetch_write_cfg3_4slices_v2_slice_kernel.csv); cfg3, single-launch path only
-                         "traffic": (1024.0 * (2 * 4672.4 + 5747.4 + 2 * 269.5 + 512.0) * C) if (args.config == "cfg3" and C <= 3) else None,
+                         # one slice_kernel dispatch per slice -- the G -> GT copy comes out of the wrap GEMM's epilogue --, ~150 accepted
+                         # flips in the probed slices; profiles/r01_pmc_fetch_write_cfg3_4slices_v3_final.csv); cfg3, single-launch path only
+                         "traffic": (1024.0 * (2 * 4663.3 + 5747.4) * C) if (args.config == "cfg3" and C <= 3) else None,
                          "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_launch_s * 1e3,
                          "launches": upd_launches, "accepted": upd_acc,
                          "time_share_of_sweep": (upd_ms * 1e-3) / dt},
