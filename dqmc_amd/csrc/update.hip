@@ -724,7 +724,8 @@ __device__ __forceinline__ void flush_tiles_lds(double* __restrict__ G, double* 
     }
 }
 
-__global__ __launch_bounds__(256) void slice_solo_kernel(UpdateDesc d, int l, int acc_slot, int kd) {
+// resume = 1: finish a slice that scan / flush kernel pairs have walked up to state[0] (exits at once when nothing is left)
+__global__ __launch_bounds__(256) void slice_solo_kernel(UpdateDesc d, int l, int acc_slot, int kd, int resume) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int chain = blockIdx.y;
     const int n = d.n;
@@ -732,6 +733,8 @@ __global__ __launch_bounds__(256) void slice_solo_kernel(UpdateDesc d, int l, in
     double* __restrict__ GT = d.GT.at(chain);
     const int j = threadIdx.x, lane = j & 63, wave = j >> 6;
     const bool live = j < n;
+    int pos = resume ? d.state[(long)chain * d.state_stride] : 0;
+    if (pos >= n) return;                                             // wave-uniform: the pairs already finished this chain's slice
     ScanShared sh;
     scan_shared_init(sh, smem, n, kd, true);
     const double* tab_g = reinterpret_cast<const double*>(d.tabs + chain);
@@ -739,6 +742,7 @@ __global__ __launch_bounds__(256) void slice_solo_kernel(UpdateDesc d, int l, in
     int8_t* fields_g = d.fields + (long)chain * d.f_stride + slice_off;
     double dg = 0.0;
     if (live) {
+        // (resume: sites are visited once per slice, so the fields of the proposals still ahead are the ones the slice started with)
         const long off = (long)chain * d.rs_stride + slice_off + j;
         const int i = d.perm[off];
         const int kp = d.kprop[off];
@@ -750,7 +754,7 @@ __global__ __launch_bounds__(256) void slice_solo_kernel(UpdateDesc d, int l, in
     }
     if (j < 32) sh.tl[j] = tab_g[j];
     __syncthreads();
-    int pos = 0, total_acc = 0;
+    int total_acc = 0;
     const int tiles16 = (n + 15) / 16;
 #ifdef DQ_SCAN_STAMPS
     ScanProf prof;
@@ -768,7 +772,7 @@ __global__ __launch_bounds__(256) void slice_solo_kernel(UpdateDesc d, int l, in
         if (live) { dg = G[j + (long)n * j]; sh.diag[j] = dg; }
         __syncthreads();
     }
-    if (j == 0) d.acc_out[(long)chain * d.acc_stride + acc_slot] = total_acc;
+    if (j == 0) { int* acc = d.acc_out + (long)chain * d.acc_stride + acc_slot; *acc = (resume ? *acc : 0) + total_acc; }
 }
 
 static int pick_kd(int n) {
@@ -814,11 +818,15 @@ int launch_update_slice(const UpdateDesc& d, int l, int acc_slot, int n_chains, 
     if (regs && !pairs && !multi_kernel && (n_chains >= 224 || solo_forced)) {
         static bool solo_attr = false;
         if (!solo_attr) { DQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(slice_solo_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); solo_attr = true; }
-        hipLaunchKernelGGL(slice_solo_kernel, dim3(1, n_chains), dim3(256), lds, s, d, l, acc_slot, kd);
+        hipLaunchKernelGGL(slice_solo_kernel, dim3(1, n_chains), dim3(256), lds, s, d, l, acc_slot, kd, 0);
         DQ_HIP(hipGetLastError());
         return 0;
     }
-    const int windows = (n + kd - 1) / kd;
+    int windows = (n + kd - 1) / kd;
+    // a thermalised slice ends after ~4 windows; the scan / flush pairs past that point are launches that find nothing to do (8 of 16
+    // at cfg 3).  Four pairs, then ONE solo launch that finishes whatever a chain has left (usually nothing: it exits at once).
+    const bool tail_solo = regs && !multi_kernel && windows > 4;
+    if (tail_solo) windows = 4;
     for (int w = 0; w < windows; ++w) {
         if (regs) {
             hipLaunchKernelGGL(scan_kernel<256>, dim3(1, n_chains), dim3(threads), lds, s, d, l, acc_slot, w == 0 ? 1 : 0, kd);
@@ -827,6 +835,11 @@ int launch_update_slice(const UpdateDesc& d, int l, int acc_slot, int n_chains, 
             hipLaunchKernelGGL(scan_kernel<1024>, dim3(1, n_chains), dim3(threads), lds, s, d, l, acc_slot, w == 0 ? 1 : 0, kd);
             hipLaunchKernelGGL(flush_kernel<false>, dim3(tiles * tiles, n_chains), dim3(256), 0, s, d, tiles, kd);
         }
+    }
+    if (tail_solo) {
+        static bool solo_attr2 = false;
+        if (!solo_attr2) { DQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(slice_solo_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); solo_attr2 = true; }
+        hipLaunchKernelGGL(slice_solo_kernel, dim3(1, n_chains), dim3(256), lds, s, d, l, acc_slot, kd, 1);
     }
     DQ_HIP(hipGetLastError());
     return 0;
