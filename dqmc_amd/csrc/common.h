@@ -120,6 +120,13 @@ int launch_lu(Mat A, int* perm, long perm_stride, double* logabsdet, int accumul
 //           triangular back substitution (no factorisation needed).
 int launch_lu_solve(CMat LU, const int* perm, long perm_stride, Mat X, CVec dg, int mode, int n, int n_chains, hipStream_t s);
 
+// ---- lu_gj.hip ----------------------------------------------------------------
+// X = A^-1 B for n <= 256 by blocked Gauss-Jordan elimination with partial pivoting (no substitution phase); A and B
+// are destroyed.  SA: n*n scratch per chain, tinv: 2048 doubles per chain, perm / rowpos: n ints per chain.
+// logabsdet (optional): (+)= log|det A|.  *info |= 1 on a zero / NaN pivot.
+int launch_gj_solve(Mat A, Mat B, Mat X, Mat SA, double* tinv, int* perm, long perm_stride, int* rowpos, long rowpos_stride,
+                    double* logabsdet, int accumulate_logdet, int* info, int n, int n_chains, hipStream_t s);
+
 // ---- update.hip ---------------------------------------------------------------
 struct UpdateTables {            // per chain, 64 doubles: model constants the slice kernel needs
     // rb[old][k]   = (gamma[new]/gamma[old]) * exp(alpha*g*(eta[new]-eta[old]))   (source/model.cpp:99-122)

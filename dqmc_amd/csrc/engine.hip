@@ -11,6 +11,7 @@
 #include "../../include/dqmc_hip.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -50,6 +51,8 @@ struct Ctx {
     double* spool = nullptr;                   // scalars: 4 * C
     unsigned long long* qsync = nullptr;       // cooperative QRCP records
     int* qabort = nullptr;                     // cooperative QRCP abort words: C
+    double* tinv = nullptr;                    // Gauss-Jordan panel inverses: 2048 * C
+    bool use_gj = false;                       // n <= 256: solves go through lu_gj.hip (DQMC_LU_CLASSIC=1 keeps dgetrf + dgetrs)
 
     Mat T(int k) const { return Mat{pool + (long)k * C * nn, nn}; }
     Vec V(int k) const { return Vec{vpool + (long)k * C * n, (long)n}; }
@@ -70,6 +73,8 @@ struct Ctx {
         DQ_HIP(hipMalloc(&spool, sizeof(double) * 4 * C));
         DQ_HIP(hipMalloc(&qsync, sizeof(unsigned long long) * qrcp_coop_sync_granules() * C));
         DQ_HIP(hipMalloc(&qabort, sizeof(int) * C));
+        DQ_HIP(hipMalloc(&tinv, sizeof(double) * 2048 * C));
+        use_gj = n <= 256 && getenv("DQMC_LU_CLASSIC") == nullptr;
         DQ_HIP(hipMemsetAsync(ipool, 0, sizeof(int) * (3L * C * n + 4), stream));
         return 0;
     }
@@ -80,6 +85,7 @@ struct Ctx {
         if (spool) (void)hipFree(spool);
         if (qsync) (void)hipFree(qsync);
         if (qabort) (void)hipFree(qabort);
+        if (tinv) (void)hipFree(tinv);
         if (stream) (void)hipStreamDestroy(stream);
     }
 
@@ -128,6 +134,17 @@ struct Ctx {
         DQ_TRY(gemm(F1.L, T(1), out.L));
         return gemm(T(2), F2.R, out.R);
     }
+    // Y = M^-1 RHS (arma::solve): blocked Gauss-Jordan for n <= 256 (result in T9's neighbour `out`), dgetrf + dgetrs otherwise
+    // (result overwrites RHS).  Returns the matrix holding Y in *Y.  M and RHS are destroyed.  (uses T9 as scratch)
+    int solve(Mat M, Mat RHS, Mat out, double* logdet_acc, Mat* Y) {
+        if (use_gj) {
+            DQ_TRY(launch_gj_solve(M, RHS, out, T(9), tinv, lperm(), n, rowpos(), n, logdet_acc, 1, info(), n, C, stream));
+            *Y = out; return 0;
+        }
+        DQ_TRY(launch_lu(M, lperm(), n, logdet_acc, 1, info(), n, C, stream, rowpos(), n));
+        DQ_TRY(launch_lu_solve(M, lperm(), n, RHS, CVec(), 0, n, C, stream));
+        *Y = RHS; return 0;
+    }
     // stablelinalg::inv_I_plus_ldr (source/stablelinalg.cpp:94-126)   (uses T0..T4, V0,V1)
     // G = X M^-1 is evaluated as the reference does, through the transposed system M^T G^T = X^T;
     // log|det M| comes from that same factorisation (det M^T = det M).
@@ -136,10 +153,9 @@ struct Ctx {
         DQ_TRY(r_inverse_scaled(F, V(0), T(1), T(0)));                                  // X = R^-1 diag(1/Dl)
         DQ_TRY(launch_add_scaled_cols(T(1), F.L, V(1), T(2), n, C, stream));            // M = X + L diag(Ds)
         DQ_TRY(launch_transpose_scale(T(2), T(3), CVec(), n, C, stream));               // M^T
-        DQ_TRY(launch_lu(T(3), lperm(), n, logdet, 1, info(), n, C, stream, rowpos(), n));           // logdet += log|det M|
         DQ_TRY(launch_transpose_scale(T(1), T(4), CVec(), n, C, stream));               // X^T
-        DQ_TRY(launch_lu_solve(T(3), lperm(), n, T(4), CVec(), 0, n, C, stream));       // G^T
-        return launch_transpose_scale(T(4), G, CVec(), n, C, stream);
+        Mat Y; DQ_TRY(solve(T(3), T(4), T(0), logdet, &Y));                             // G^T; logdet += log|det M|
+        return launch_transpose_scale(Y, G, CVec(), n, C, stream);
     }
     // stablelinalg::inv_I_plus_ldr_mul_ldr (source/stablelinalg.cpp:128-158)   (uses T0..T3, V0..V3)
     int inv_I_plus_ldr_mul_ldr(LdrRef F1, LdrRef F2, Mat G) {
@@ -149,9 +165,8 @@ struct Ctx {
         DQ_TRY(gemm(F1.L, T(1), T(2), V(0), CVec(), CVec(), 1));                        // TermA = diag(1/D1l) L1^T X
         DQ_TRY(gemm(F1.R, F2.L, T(2), V(1), CVec(), V(3), 0, 1));                       // M = TermA + diag(D1s) R1 L2 diag(D2s)
         DQ_TRY(launch_transpose_scale(F1.L, T(3), V(0), n, C, stream));                 // RHS = diag(1/D1l) L1^T
-        DQ_TRY(launch_lu(T(2), lperm(), n, nullptr, 0, info(), n, C, stream, rowpos(), n));
-        DQ_TRY(launch_lu_solve(T(2), lperm(), n, T(3), CVec(), 0, n, C, stream));       // Y = M^-1 RHS
-        return gemm(T(1), T(3), G);                                                     // G = X Y
+        Mat Y; DQ_TRY(solve(T(2), T(3), T(0), nullptr, &Y));                            // Y = M^-1 RHS
+        return gemm(T(1), Y, G);                                                        // G = X Y
     }
     // stablelinalg::inv_invldr_plus_ldr (source/stablelinalg.cpp:160-190): G = [F1^-1 + F2]^-1 (negated on request)   (uses T0..T3, V0..V3)
     int inv_invldr_plus_ldr(LdrRef F1, LdrRef F2, Mat G, bool negate) {
@@ -161,9 +176,8 @@ struct Ctx {
         DQ_TRY(gemm(F1.L, T(1), T(2), V(0), CVec(), CVec(), 1));                        // TermA = diag(1/D1l) L1^T X
         DQ_TRY(gemm(F1.R, F2.L, T(2), V(1), CVec(), V(3), 0, 1));                       // M = TermA + diag(D1s) R1 L2 diag(D2s)
         DQ_TRY(launch_scale_rows(F1.R, V(1), T(3), n, C, stream));                      // RHS = diag(D1s) R1
-        DQ_TRY(launch_lu(T(2), lperm(), n, nullptr, 0, info(), n, C, stream, rowpos(), n));
-        DQ_TRY(launch_lu_solve(T(2), lperm(), n, T(3), CVec(), 0, n, C, stream));       // Y = M^-1 RHS
-        DQ_TRY(gemm(T(1), T(3), G));                                                    // G = X Y
+        Mat Y; DQ_TRY(solve(T(2), T(3), T(0), nullptr, &Y));                            // Y = M^-1 RHS
+        DQ_TRY(gemm(T(1), Y, G));                                                       // G = X Y
         if (negate) DQ_TRY(launch_axpb_identity(G, G, -1.0, 0.0, n, C, stream));
         return 0;
     }

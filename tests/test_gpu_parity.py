@@ -350,7 +350,8 @@ def test_set_G_and_reinit_are_consistent(hip, orc):
 
 
 def test_alternative_kernel_paths_in_subprocess(hip):
-    """The opt-in / fallback kernels (cooperative 8-workgroup QRCP, block-cyclic QRCP, streaming QRCP, streaming LU, one-wave-per-tile
+    """The opt-in / fallback kernels (cooperative 8-workgroup QRCP, block-cyclic QRCP, streaming QRCP, streaming LU, dgetrf + dgetrs instead of the
+    blocked Gauss-Jordan solve, one-wave-per-tile
     GEMM, scan / flush kernel pairs instead of the single-launch slice kernel)
     are selected by environment switches read once per process: run them in child processes and check cfg-3 init parity
     against the default path (itself checked against the oracle above)."""
@@ -374,7 +375,8 @@ def test_alternative_kernel_paths_in_subprocess(hip):
         assert out.returncode == 0, out.stderr[-2000:]
         return json.loads(out.stdout.strip().splitlines()[-1])
     ref = run({})
-    for env in ({"DQMC_QR_COOP": "1"}, {"DQMC_QR_BLOCKCYCLIC": "1"}, {"DQMC_QR_STREAMING": "1"}, {"DQMC_LU_STREAMING": "1"}, {"DQMC_GEMM_V1": "1"},
+    for env in ({"DQMC_QR_COOP": "1"}, {"DQMC_QR_BLOCKCYCLIC": "1"}, {"DQMC_QR_STREAMING": "1"}, {"DQMC_LU_STREAMING": "1"}, {"DQMC_LU_CLASSIC": "1"},
+                {"DQMC_LU_CLASSIC": "1", "DQMC_LU_STREAMING": "1"}, {"DQMC_GEMM_V1": "1"},
                 {"DQMC_SLICE_MULTIKERNEL": "1"}, {"DQMC_SLICE_SOLO": "1"}):
         got = run(env)
         assert abs(got["ld"] - ref["ld"]) < 1e-8 * abs(ref["ld"]), (env, got, ref)
