@@ -6,12 +6,13 @@
 //
 //   gj_panel_kernel   ONE wave per chain.  Lane owns rows lane, lane+64, ... of the panel in
 //                     registers and runs dgetf2 on the live rows (pivot search = per-lane max +
-//                     DPP wave max, pivot row broadcast through LDS; a single wave needs no
-//                     barrier).  A is NOT modified: the kernel emits the pivot rows S of the
-//                     panel, log|det| of the pivot block P11 = L11 U11 and the two triangular
-//                     inverses L11^-1, U11^-1 (32 x 32 each, one column per lane).
+//                     32-bit DPP wave maxima + ballot, pivot row broadcast by v_readlane into
+//                     SGPRs: no LDS, no barrier, no memory access in the step loop).  A is NOT
+//                     modified: the kernel emits the pivot rows S of the panel, log|det| of the
+//                     pivot block P11 = L11 U11, the block itself and the inverses of its four
+//                     16 x 16 diagonal triangles (one column per lane).
 //   gj_update_kernel  whole chip, fp64 MFMA.  Every wave forms, for its 16 columns,
-//                     U12 = U11^-1 (L11^-1 A[S, cols]) with the matrix cores (the pivot rows
+//                     U12 = U11^-1 (L11^-1 A[S, cols]) by block substitution on the matrix cores (the pivot rows
 //                     are read-only in this launch) and subtracts A[r, panel] U12 from every
 //                     other row r -- the live rows of A and B, and the rows retired by earlier
 //                     panels.  Retired rows live in pivot order in SA | X, so that after the
@@ -32,71 +33,87 @@ namespace {
 constexpr int GJ_NB = 32;
 using d4 = __attribute__((ext_vector_type(4))) double;
 
-__device__ __forceinline__ unsigned long long gj_key(double a, int r) {
-    // |a| as an ordered unsigned integer; the low 10 bits carry 1023 - row so equal magnitudes pick the lowest row (idamax)
-    return ((unsigned long long)__double_as_longlong(fabs(a)) & ~0x3FFULL) | (unsigned long long)(1023 - r) | (1ULL << 63);
-}
 __device__ __forceinline__ void lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
-// One elimination step of the panel, J a compile-time constant so that every register index is static
-// (a rolled or partially unrolled step loop would put the panel into scratch).
+// max over the 64 lanes of a 32-bit unsigned key (wave-uniform result): one v_max_u32 with a DPP operand per stage
+__device__ __forceinline__ unsigned wave_max_u32(unsigned k) {
+#define DQ_MAX32(CTRL, MASK) { const unsigned o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)k, CTRL, MASK, 0xf, false); k = o > k ? o : k; }
+    DQ_MAX32(0xB1, 0xf)        // quad_perm [1,0,3,2]
+    DQ_MAX32(0x4E, 0xf)        // quad_perm [2,3,0,1]
+    DQ_MAX32(0x141, 0xf)       // row_half_mirror
+    DQ_MAX32(0x140, 0xf)       // row_mirror
+    DQ_MAX32(0x142, 0xa)       // row_bcast:15
+    DQ_MAX32(0x143, 0xc)       // row_bcast:31
+#undef DQ_MAX32
+    return (unsigned)__builtin_amdgcn_readlane((int)k, 63);
+}
+
+// One elimination step of the panel, J a compile-time constant so that every register index is static (a rolled
+// step loop would put the panel into scratch).  No LDS and no memory traffic: the pivot search is a per-lane max
+// over the lane's rows, two 32-bit DPP wave maxima (high word of |a|, then low word among the lanes that tie) and a
+// ballot; the pivot row reaches the other lanes through v_readlane into SGPRs, which the FMAs take as operands.
 template <int NR, int J>
-__device__ __forceinline__ void gj_step(double (&a)[NR][GJ_NB], bool (&live)[NR], int (&mypos)[NR], double (*LU)[GJ_NB], int* prow_idx,
-                                        int lane, int k0) {
-    unsigned long long key = 0ULL;
+__device__ __forceinline__ void gj_step(double (&a)[NR][GJ_NB], bool (&live)[NR], int (&mypos)[NR], int& myperm, bool& singular, int lane, int k0) {
+    unsigned long long best = 0ULL; int bq = -1;
 #pragma unroll
     for (int q = 0; q < NR; ++q) {
-        const unsigned long long kq = live[q] ? gj_key(a[q][J], lane + 64 * q) : 0ULL;
-        key = kq > key ? kq : key;
+        const unsigned long long kq = live[q] ? ((unsigned long long)__double_as_longlong(fabs(a[q][J])) | 1ULL) : 0ULL;   // live rows have a nonzero key
+        if (kq > best) { best = kq; bq = q; }             // strict: the lowest row of the lane wins a tie
     }
-    key = wave_max_u64(key);
-    const int p = 1023 - (int)(key & 0x3FFULL);
-    const int pl = p & 63, pq = p >> 6;
+    const unsigned hi = (unsigned)(best >> 32), lo = (unsigned)best;
+    const unsigned m1 = wave_max_u32(hi);
+    const unsigned m2 = wave_max_u32(hi == m1 ? lo : 0u);
+    const unsigned long long winners = __ballot(hi == m1 && lo == m2 && bq >= 0);
+    const int pl = winners ? (int)__builtin_ctzll(winners) : 0;             // winners == 0 only when no live row is left (n < k0 + J + 1: excluded by the caller)
+    const int pq = __builtin_amdgcn_readlane(bq, pl);
+    if (lane == J) myperm = pl + 64 * pq;
+    double prow[GJ_NB - J];
 #pragma unroll
     for (int q = 0; q < NR; ++q) {
-        if (q == pq && lane == pl) {             // the pivot row: L11[J][:J] and U11[J][J:] are final now
+        if (q == pq) {                                    // wave-uniform
 #pragma unroll
-            for (int c = 0; c < GJ_NB; c += 2) *reinterpret_cast<double2*>(&LU[J][c]) = make_double2(a[q][c], a[q][c + 1]);
-            live[q] = false; mypos[q] = k0 + J;
-            prow_idx[J] = p;
+            for (int c = J; c < GJ_NB; ++c) prow[c - J] = readlane_f64(a[q][c], pl);
         }
     }
-    lds_wait();
-    constexpr int C0 = J & ~1;
-    double prow[GJ_NB - C0];
 #pragma unroll
-    for (int c = C0; c < GJ_NB; c += 2) { const double2 v = *reinterpret_cast<const double2*>(&LU[J][c]); prow[c - C0] = v.x; prow[c + 1 - C0] = v.y; }
-    const double rpiv = 1.0 / prow[J - C0];      // dgetf2 scales by the reciprocal pivot as well
+    for (int q = 0; q < NR; ++q)
+        if (q == pq && lane == pl) { live[q] = false; mypos[q] = k0 + J; }
+    const double piv = prow[0];
+    singular = singular || !(fabs(piv) > 0.0);
+    // reciprocal pivot (dgetf2 scales by the reciprocal as well): v_rcp_f64 + two Newton steps, no div_scale / div_fixup
+    double r = __builtin_amdgcn_rcp(piv);
+    r = fma(fma(-piv, r, 1.0), r, r);
+    r = fma(fma(-piv, r, 1.0), r, r);
 #pragma unroll
     for (int q = 0; q < NR; ++q) {
         if (live[q]) {
-            const double l = a[q][J] * rpiv;
+            const double l = a[q][J] * r;
             a[q][J] = l;
 #pragma unroll
-            for (int c = J + 1; c < GJ_NB; ++c) a[q][c] -= l * prow[c - C0];
+            for (int c = J + 1; c < GJ_NB; ++c) a[q][c] = fma(-l, prow[c - J], a[q][c]);
         }
     }
 }
 template <int NR, int J>
 struct GjSteps {
-    static __device__ __forceinline__ void run(double (&a)[NR][GJ_NB], bool (&live)[NR], int (&mypos)[NR], double (*LU)[GJ_NB], int* prow_idx,
-                                               int lane, int nbw, int k0) {
-        if (J < nbw) gj_step<NR, J>(a, live, mypos, LU, prow_idx, lane, k0);      // wave-uniform
-        GjSteps<NR, J + 1>::run(a, live, mypos, LU, prow_idx, lane, nbw, k0);
+    static __device__ __forceinline__ void run(double (&a)[NR][GJ_NB], bool (&live)[NR], int (&mypos)[NR], int& myperm, bool& singular, int lane, int nbw, int k0) {
+        if (J < nbw) gj_step<NR, J>(a, live, mypos, myperm, singular, lane, k0);      // wave-uniform
+        GjSteps<NR, J + 1>::run(a, live, mypos, myperm, singular, lane, nbw, k0);
     }
 };
 template <int NR>
 struct GjSteps<NR, GJ_NB> {
-    static __device__ __forceinline__ void run(double (&)[NR][GJ_NB], bool (&)[NR], int (&)[NR], double (*)[GJ_NB], int*, int, int, int) {}
+    static __device__ __forceinline__ void run(double (&)[NR][GJ_NB], bool (&)[NR], int (&)[NR], int&, bool&, int, int, int) {}
 };
 }  // namespace
 
-// tinv: per chain 2 * 32 * 32 doubles, column-major: Linv[i + 32 c], then Uinv[i + 32 c]
+// tinv: per chain 2048 doubles: [0, 1024) the pivot block LU[j][c] row-major in pivot order (L11 strictly below, U11 on and
+// above the diagonal), then the four 16 x 16 triangular inverses, column-major: L11[0:16,0:16]^-1, L11[16:32,16:32]^-1,
+// U11[0:16,0:16]^-1, U11[16:32,16:32]^-1.  Rows / columns >= nbw are the identity.
 template <int NR>
 __global__ __launch_bounds__(64) void gj_panel_kernel(CMat Am, int* rowpos_p, long rowpos_stride, int* perm_p, long perm_stride, double* tinv_p,
                                                       double* logabsdet, int accumulate, int* info, int n, int k0) {
-    __shared__ __attribute__((aligned(16))) double LU[GJ_NB][GJ_NB];      // pivot rows in pivot order: L11 below, U11 on and above the diagonal
-    __shared__ int prow_idx[GJ_NB];
+    __shared__ __attribute__((aligned(16))) double LU[GJ_NB][GJ_NB];
     const int chain = blockIdx.y;
     const double* __restrict__ A = Am.at(chain);
     int* rowpos = rowpos_p + (long)chain * rowpos_stride;
@@ -116,46 +133,57 @@ __global__ __launch_bounds__(64) void gj_panel_kernel(CMat Am, int* rowpos_p, lo
         for (int c = 0; c < GJ_NB; ++c) a[q][c] = (live[q] && c < nbw) ? A[r + (long)n * (k0 + c)] : 0.0;
     }
     for (int e = lane; e < GJ_NB * GJ_NB; e += 64) (&LU[0][0])[e] = ((e >> 5) == (e & 31)) ? 1.0 : 0.0;   // identity padding for nbw < 32
-    lds_wait();
+    int myperm = 0; bool singular = false;
 
-    GjSteps<NR, 0>::run(a, live, mypos, LU, prow_idx, lane, nbw, k0);
+    GjSteps<NR, 0>::run(a, live, mypos, myperm, singular, lane, nbw, k0);
+
+    lds_wait();                                          // the identity fill is in LDS before the pivot rows overwrite theirs
 #pragma unroll
     for (int q = 0; q < NR; ++q) {
         const int r = lane + 64 * q;
         if (r < n) { if (k0 == 0) rowpos[r] = mypos[q]; else if (mypos[q] >= 0) rowpos[r] = mypos[q]; }
+        if (mypos[q] >= 0) {                             // a pivot row: untouched since its step, L11[j][:j] | U11[j][j:]
+            double* dst = &LU[mypos[q] - k0][0];
+#pragma unroll
+            for (int c = 0; c < GJ_NB; c += 2) *reinterpret_cast<double2*>(dst + c) = make_double2(a[q][c], a[q][c + 1]);
+        }
     }
+    if (lane < nbw) perm[k0 + lane] = myperm;
     lds_wait();
-    if (lane < nbw) perm[k0 + lane] = prow_idx[lane];
+#pragma unroll
+    for (int e = 0; e < GJ_NB * GJ_NB / 64; ++e) tinv[lane + 64 * e] = (&LU[0][0])[lane + 64 * e];
     {                                                    // log|det P11| and singularity check
         const double pv = lane < nbw ? fabs(LU[lane][lane]) : 1.0;
         const double ls = wave_sum(log(pv));
-        const bool bad = __any(!(pv > 0.0));
         if (lane == 0) {
             if (logabsdet) logabsdet[chain] = ((accumulate || k0 > 0) ? logabsdet[chain] : 0.0) + ls;
-            if (info && bad) atomicOr(info, 1);
+            if (info && (singular || !(ls == ls))) atomicOr(info, 1);
         }
     }
-    // Triangular inverses, one column per lane: lanes 0..31 column c of L11^-1 (forward substitution), lanes 32..63
-    // column c of U11^-1 run as the same forward recurrence on the index-reversed matrix.  Rows / columns >= nbw of
-    // LU are the identity, so both inverses are identity-padded as well.
+    // The four 16 x 16 triangular inverses, one column per lane (lane = 16 * block + column): unit-lower blocks by forward
+    // substitution, upper blocks by the same recurrence on the index-reversed block.
     {
-        const bool up = lane >= 32;
-        const int c = lane & 31;
-        const int cc = up ? 31 - c : c;                  // unit vector position in recurrence order
-        double x[GJ_NB];
+        const int blk = lane >> 4, c = lane & 15;
+        const bool up = blk >= 2;
+        const int base = (blk & 1) * 16;
+        const double* T0 = &LU[0][0] + (up ? (base + 15) * 33 : base * 33);
+        const int sg = up ? -1 : 1;
+        const int cc = up ? 15 - c : c;                  // position of the unit vector's 1 in recurrence order
+        double x[16];
 #pragma unroll
-        for (int j = 0; j < GJ_NB; ++j) {
-            double s = (j == cc) ? 1.0 : 0.0;
+        for (int j = 0; j < 16; ++j) {
+            double s0 = (j == cc) ? 1.0 : 0.0, s1 = 0.0;
 #pragma unroll
             for (int m = 0; m < j; ++m) {
-                const double t = up ? LU[31 - j][31 - m] : LU[j][m];
-                s -= t * x[m];
+                const double t = T0[sg * (j * 32 + m)];
+                if (m & 1) s1 = fma(-t, x[m], s1); else s0 = fma(-t, x[m], s0);
             }
-            x[j] = up ? s / LU[31 - j][31 - j] : s;
+            const double s = s0 + s1;
+            x[j] = up ? s / T0[sg * (j * 33)] : s;
         }
-        double* out = tinv + (up ? GJ_NB * GJ_NB : 0) + 32 * c;
+        double* out = tinv + GJ_NB * GJ_NB + 256 * blk + 16 * c;
 #pragma unroll
-        for (int j = 0; j < GJ_NB; ++j) out[up ? 31 - j : j] = x[j];
+        for (int j = 0; j < 16; ++j) out[up ? 15 - j : j] = x[j];
     }
 }
 
@@ -176,8 +204,8 @@ __global__ __launch_bounds__(256) void gj_update_kernel(Mat Am, Mat Bm, Mat SAm,
     double* __restrict__ X = Xm.at(chain);
     const int* rowpos = rowpos_p + (long)chain * rowpos_stride;
     const int* perm = perm_p + (long)chain * perm_stride;
-    const double* __restrict__ Linv = tinv_p + (long)chain * 2 * GJ_NB * GJ_NB;
-    const double* __restrict__ Uinv = Linv + GJ_NB * GJ_NB;
+    const double* __restrict__ LUg = tinv_p + (long)chain * 2 * GJ_NB * GJ_NB;      // pivot block, row-major
+    const double* __restrict__ Tinv = LUg + GJ_NB * GJ_NB;                          // 4 x (16 x 16) triangular inverses, column-major
     const int nbw = min(GJ_NB, n - k0);
     const int row_tiles = nA + nS + 1;
     const int rt = blockIdx.x % row_tiles, ct = blockIdx.x / row_tiles;
@@ -230,28 +258,39 @@ __global__ __launch_bounds__(256) void gj_update_kernel(Mat Am, Mat Bm, Mat SAm,
             cold[reg] = dst[rc + coff];
         }
     }
-    // ---- T1 = L11^-1 A12 (lower triangular: the upper row half needs k < 16 only) ----
-    d4 t1[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+    // ---- triangular operands (A operand of the MFMA: row r16, k = 4 s + kk) ----
+    double lai[4], lbi[4], uai[4], ubi[4], cl[4], cu[4];
 #pragma unroll
-    for (int hp = 0; hp < 2; ++hp)
+    for (int s = 0; s < 4; ++s) {
+        const int k = 4 * s + kk;
+        lai[s] = Tinv[0 * 256 + r16 + 16 * k]; lbi[s] = Tinv[1 * 256 + r16 + 16 * k];
+        uai[s] = Tinv[2 * 256 + r16 + 16 * k]; ubi[s] = Tinv[3 * 256 + r16 + 16 * k];
+        cl[s] = -LUg[(16 + r16) * 32 + k];               // -L11[16 + r16][k]
+        cu[s] = -LUg[r16 * 32 + 16 + k];                 // -U11[r16][16 + k]
+    }
+    // ---- T1 = L11^-1 A12 by block forward substitution.  The B-operand chunking k = 4 s + kk is the D layout
+    //      (row kk + 4 reg), so a12[1] seeds the accumulator of the Schur step directly. ----
+    const d4 zero4 = {0.0, 0.0, 0.0, 0.0};
+    d4 t1[2], u[2];
+    t1[0] = zero4;
 #pragma unroll
-        for (int h = 0; h <= hp; ++h)
+    for (int s = 0; s < 4; ++s) t1[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(lai[s], a12[0][s], t1[0], 0, 0, 0);
+    d4 w = {a12[1][0], a12[1][1], a12[1][2], a12[1][3]};
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const double lv = Linv[(16 * hp + r16) + 32 * (16 * h + 4 * s + kk)];
-                t1[hp] = __builtin_amdgcn_mfma_f64_16x16x4f64(lv, a12[h][s], t1[hp], 0, 0, 0);
-            }
-    // ---- U12 = U11^-1 T1 (upper triangular: the lower row half needs k >= 16 only); B operand = t1[h][reg], k = 16h + kk + 4 reg ----
-    d4 u[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+    for (int s = 0; s < 4; ++s) w = __builtin_amdgcn_mfma_f64_16x16x4f64(cl[s], t1[0][s], w, 0, 0, 0);
+    t1[1] = zero4;
 #pragma unroll
-    for (int hp = 0; hp < 2; ++hp)
+    for (int s = 0; s < 4; ++s) t1[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(lbi[s], w[s], t1[1], 0, 0, 0);
+    // ---- U12 = U11^-1 T1 by block back substitution ----
+    u[1] = zero4;
 #pragma unroll
-        for (int h = hp; h < 2; ++h)
+    for (int s = 0; s < 4; ++s) u[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(ubi[s], t1[1][s], u[1], 0, 0, 0);
+    w = t1[0];
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const double uv = Uinv[(16 * hp + r16) + 32 * (16 * h + kk + 4 * reg)];
-                u[hp] = __builtin_amdgcn_mfma_f64_16x16x4f64(uv, t1[h][reg], u[hp], 0, 0, 0);
-            }
+    for (int s = 0; s < 4; ++s) w = __builtin_amdgcn_mfma_f64_16x16x4f64(cu[s], u[1][s], w, 0, 0, 0);
+    u[0] = zero4;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) u[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(uai[s], w[s], u[0], 0, 0, 0);
     if (writer) {                                            // rows k0 + 16 wr + kk + 4 reg of SA / X receive U12
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
