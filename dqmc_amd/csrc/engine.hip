@@ -52,7 +52,7 @@ struct Ctx {
     unsigned long long* qsync = nullptr;       // cooperative QRCP records
     int* qabort = nullptr;                     // cooperative QRCP abort words: C
     double* tinv = nullptr;                    // Gauss-Jordan panel inverses: 2048 * C
-    bool use_gj = false;                       // n <= 256: solves go through lu_gj.hip (DQMC_LU_CLASSIC=1 keeps dgetrf + dgetrs)
+    bool use_gj = false;                       // n <= 256, few chains: solves go through lu_gj.hip (DQMC_LU_CLASSIC=1 keeps dgetrf + dgetrs)
 
     Mat T(int k) const { return Mat{pool + (long)k * C * nn, nn}; }
     Vec V(int k) const { return Vec{vpool + (long)k * C * n, (long)n}; }
@@ -74,7 +74,9 @@ struct Ctx {
         DQ_HIP(hipMalloc(&qsync, sizeof(unsigned long long) * qrcp_coop_sync_granules() * C));
         DQ_HIP(hipMalloc(&qabort, sizeof(int) * C));
         DQ_HIP(hipMalloc(&tinv, sizeof(double) * 2048 * C));
-        use_gj = n <= 256 && getenv("DQMC_LU_CLASSIC") == nullptr;
+        // latency regime only: with many chains per launch the blocked LU + per-column substitution has the higher throughput
+        // (128 chains, cfg 3: 458 ms per step against 483 ms with the single-wave panels)
+        use_gj = n <= 256 && C <= 8 && getenv("DQMC_LU_CLASSIC") == nullptr;
         DQ_HIP(hipMemsetAsync(ipool, 0, sizeof(int) * (3L * C * n + 4), stream));
         return 0;
     }
