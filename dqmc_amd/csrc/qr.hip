@@ -233,6 +233,101 @@ __global__ __launch_bounds__(256) void formq_kernel(CMat Am, const double* tau_p
     }
 }
 
+// formq for n = 16 * NRR exactly (n = 16, 32, 64, 128, 256): the reflectors are walked in blocks of 16 (block M = reflectors 16M .. 16M+15),
+// one code variant per block, so that register indices stay static while
+//   * rows below the block (j < M) are neither loaded nor multiplied: H_i only touches rows >= i -- half the work on average,
+//   * only the row groups j = M - 1, M need the "rows <= i hold R, row i is the implicit 1" mask; j > M is loaded as it is.
+// The ring of four prefetched reflectors runs across block boundaries (a block's fetches include row group M - 1 for that).
+// The dot product uses two accumulators (a single chain of dependent fp64 FMAs costs its full latency per term).
+template <int NRR, int M>
+struct FormQBlock {
+    static constexpr int J0 = M > 0 ? M - 1 : 0;
+    static __device__ __forceinline__ void fetch(double (&v)[NRR], double& t, const double* __restrict__ A, const int* s_jpvt, const double* s_tau,
+                                                 int n, int rg, int ii) {
+        const int ic = ii > 0 ? ii : 0;                      // clamped: harmless reload past the end
+        const long cb = (long)n * s_jpvt[ic]; t = s_tau[ic];
+#pragma unroll
+        for (int j = J0; j < NRR; ++j) {
+            const int r = 16 * j + rg;
+            const double x = A[r + cb];
+            v[j] = (j > M) ? x : ((r > ic) ? x : (r == ic ? 1.0 : 0.0));
+        }
+    }
+    static __device__ __forceinline__ void apply(double (&q)[NRR], const double (&v)[NRR], double ti, int c, int i) {
+        if (ti == 0.0) return;
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int j = M; j < NRR; ++j) { if ((j - M) & 1) s1 = fma(v[j], q[j], s1); else s0 = fma(v[j], q[j], s0); }
+        double s = row16_sum(s0 + s1) * ti;
+        if (c < i) s = 0.0;                                  // column still e_c: untouched by H_i
+#pragma unroll
+        for (int j = M; j < NRR; ++j) q[j] = fma(-s, v[j], q[j]);
+    }
+    static __device__ __forceinline__ void run(double (&q)[NRR], double (&vq)[4][NRR], double (&tq)[4], const double* __restrict__ A, const int* s_jpvt,
+                                               const double* s_tau, int n, int rg, int c, int cw_max) {
+        const int mtop = cw_max >> 4;
+        if (M <= mtop) {                                     // wave-uniform
+            const int hi = M == mtop ? cw_max : 16 * M + 15;
+            if (M == mtop) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) fetch(vq[e], tq[e], A, s_jpvt, s_tau, n, rg, hi - e);
+            }
+            for (int top = hi; top >= 16 * M; top -= 4) {    // (hi + 1) is a multiple of 4: whole groups
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    apply(q, vq[e], tq[e], c, top - e);
+                    fetch(vq[e], tq[e], A, s_jpvt, s_tau, n, rg, top - e - 4);
+                }
+            }
+        }
+        FormQBlock<NRR, M - 1>::run(q, vq, tq, A, s_jpvt, s_tau, n, rg, c, cw_max);
+    }
+};
+template <int NRR>
+struct FormQBlock<NRR, -1> {
+    static __device__ __forceinline__ void run(double (&)[NRR], double (&)[4][NRR], double (&)[4], const double*, const int*, const double*, int, int, int, int) {}
+};
+template <int NRR>
+__global__ __launch_bounds__(256) void formq_blocked_kernel(CMat Am, const double* tau_p, long tau_stride, const int* jpvt_p, long jpvt_stride, Mat Qm, int n) {
+    const int chain = blockIdx.y;
+    const double* __restrict__ A = Am.at(chain);
+    const double* __restrict__ tau = tau_p + (long)chain * tau_stride;
+    const int* __restrict__ jpvt = jpvt_p + (long)chain * jpvt_stride;
+    double* __restrict__ Q = Qm.at(chain);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rg = lane & 15, cq = lane >> 4;
+    const int c = blockIdx.x * 16 + wave * 4 + cq;             // my column (< n: n is a multiple of 16)
+    const int cw_max = blockIdx.x * 16 + wave * 4 + 3;         // largest column of this wave
+    __shared__ int s_jpvt[256];
+    __shared__ double s_tau[256];
+    for (int k = threadIdx.x; k < n; k += blockDim.x) { s_jpvt[k] = jpvt[k]; s_tau[k] = tau[k]; }
+    __syncthreads();
+    double q[NRR];
+#pragma unroll
+    for (int j = 0; j < NRR; ++j) q[j] = (16 * j + rg == c) ? 1.0 : 0.0;
+    double vq[4][NRR]; double tq[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        tq[e] = 0.0;
+#pragma unroll
+        for (int j = 0; j < NRR; ++j) vq[e][j] = 0.0;
+    }
+    FormQBlock<NRR, NRR - 1>::run(q, vq, tq, A, s_jpvt, s_tau, n, rg, c, cw_max);
+#pragma unroll
+    for (int j = 0; j < NRR; ++j) { const int r = 16 * j + rg; if (r < n) Q[r + (long)n * c] = q[j]; }
+}
+
+static bool formq_blocked_ok(int n) {
+    static const bool off = getenv("DQMC_FORMQ_CLASSIC") != nullptr;     // A/B switch
+    return !off && (n == 16 || n == 32 || n == 64 || n == 128 || n == 256);      // NRR = n / 16 exactly: no row bound checks in the kernel
+}
+static void launch_formq_blocked(CMat A, const QrWork& w, Mat L, int n, int n_chains, hipStream_t s) {
+    const dim3 grid(n / 16, n_chains), block(256);
+#define DQ_FQ(NRR) hipLaunchKernelGGL((formq_blocked_kernel<NRR>), grid, block, 0, s, A, (const double*)w.tau, w.tau_stride, (const int*)w.jpvt, w.jpvt_stride, L, n)
+    if (n <= 16) DQ_FQ(1); else if (n <= 32) DQ_FQ(2); else if (n <= 64) DQ_FQ(4); else if (n <= 128) DQ_FQ(8); else DQ_FQ(16);
+#undef DQ_FQ
+}
+
 // d[j] = |R0[j,j]|;  R[:, jpvt[j]] = R0[:, j] / d   (source/stablelinalg.cpp:47-52).
 // Without column swaps R0[:, j] sits in column jpvt[j] of A, which is also its destination.
 __global__ void assemble_r_kernel(CMat Am, const int* jpvt_p, long jpvt_stride, Vec dv, Mat Rm, int n) {
@@ -268,8 +363,9 @@ static int launch_to_ldr_nr(Mat A, Mat L, Vec d, Mat R, QrWork w, int n, int n_c
         if (n > 128 && w.sync && use_coop && 8 * n_chains <= 2048) DQ_TRY_RC(launch_qrcp_coop(A, w, n, n_chains, s));
         else if (use_blockcyclic) DQ_TRY_RC(launch_qrcp_onchip(A, w, n, n_chains, s));
         else DQ_TRY_RC(launch_qrcp_colown(A, w, n, n_chains, s));
-        hipLaunchKernelGGL((formq_kernel<4 * NR>), dim3((n + 15) / 16, n_chains), dim3(256), 0, s, CMat(A), (const double*)w.tau, w.tau_stride,
-                           (const int*)w.jpvt, w.jpvt_stride, L, n);
+        if (formq_blocked_ok(n)) launch_formq_blocked(CMat(A), w, L, n, n_chains, s);
+        else hipLaunchKernelGGL((formq_kernel<4 * NR>), dim3((n + 15) / 16, n_chains), dim3(256), 0, s, CMat(A), (const double*)w.tau, w.tau_stride,
+                                (const int*)w.jpvt, w.jpvt_stride, L, n);
         hipLaunchKernelGGL(assemble_r_kernel, dim3(n, n_chains), dim3(128), 0, s, CMat(A), (const int*)w.jpvt, w.jpvt_stride, d, R, n);
         DQ_HIP(hipGetLastError());
         return 0;
