@@ -18,11 +18,11 @@ $(CSRC)/qr_colown_regs.inc: scripts/gen_qr_colown_regs.py
 dqmc_amd/libdqmc_hip.so: $(OBJS)
 	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ $(OBJS)
 
-dqmc_amd/libdqmc_host.so: dqmc_amd/host/host_capi.cpp dqmc_amd/host/dqmc_host.hpp include/dqmc_hip.h
+dqmc_amd/libdqmc_host.so: dqmc_amd/host/host_capi.cpp dqmc_amd/host/dqmc_host.hpp dqmc_amd/host/results_h5.hpp include/dqmc_hip.h
 	$(CXX) -O2 -std=c++17 -fPIC -shared -Iinclude -Idqmc_amd/host -o $@ dqmc_amd/host/host_capi.cpp -ldl
 
-dqmc_amd/dqmc_driver: dqmc_amd/host/main.cpp dqmc_amd/host/dqmc_host.hpp include/dqmc_hip.h dqmc_amd/libdqmc_hip.so
-	$(CXX) -O2 -std=c++17 -Iinclude -Idqmc_amd/host -o $@ dqmc_amd/host/main.cpp -Ldqmc_amd -ldqmc_hip -Wl,-rpath,'$$ORIGIN'
+dqmc_amd/dqmc_driver: dqmc_amd/host/main.cpp dqmc_amd/host/dqmc_host.hpp dqmc_amd/host/results_h5.hpp include/dqmc_hip.h dqmc_amd/libdqmc_hip.so
+	$(CXX) -O2 -std=c++17 -Iinclude -Idqmc_amd/host -o $@ dqmc_amd/host/main.cpp -Ldqmc_amd -ldqmc_hip -ldl -Wl,-rpath,'$$ORIGIN'
 
 oracle:
 	$(MAKE) -C oracle

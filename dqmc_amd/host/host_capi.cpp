@@ -2,6 +2,7 @@
 // CPU test-suite can exercise the host logic (RNG stream semantics, INI reader,
 // model constants, replica pairing) without a GPU.  No HIP, no oracle.
 #include "dqmc_host.hpp"
+#include "results_h5.hpp"
 
 extern "C" {
 
@@ -84,6 +85,45 @@ int dqmc_host_param(const char* ini, const char* section, const char* key, int k
         else if (kind == 2) *out = p.getBool(section, key) ? 1.0 : 0.0;
         else *out = (double)p.getDoubleVector(section, key).size();
         return 0;
+    } catch (const std::exception& e) {
+        if (err && errlen > 0) { std::strncpy(err, e.what(), errlen - 1); err[errlen - 1] = 0; }
+        return -1;
+    }
+}
+
+// ---- results_h5.hpp: the on-disk layout of the reference (include/measurementh5.h:277-362) ----
+// Writes n_bins bins into <dir>/data_<rank>.h5.  scalars: [n_bins][3] (density, doubleOcc, swave); chi_r: [n_bins][L1*L2];
+// unequal: NULL or [n_bins][3][n_tau][L1*L2].  The lattice (a1, a2, k-points) is the square one the driver builds.
+int dqmc_host_results_write(const char* dir, int rank, int L1, int L2, int n_bins, const double* scalars, const double* chi_r,
+                            const double* unequal, int n_tau, char* err, int errlen) {
+    try {
+        utility::parameters params = utility::parameters::from_string("[Lattice]\nL1 = " + std::to_string(L1) + "\nL2 = " + std::to_string(L2) + "\n");
+        Lattice lat(params, {1.0, 0.0}, {0.0, 1.0}, {{0.0, 0.0}});
+        ResultsWriter w(dir, rank, L1, L2, lat.a1(), lat.a2(), lat.k_points());
+        const size_t nb = (size_t)L1 * L2;
+        for (int b = 0; b < n_bins; ++b) {
+            ResultsBin bin;
+            bin.density = scalars[3 * b]; bin.doubleOcc = scalars[3 * b + 1]; bin.swave = scalars[3 * b + 2];
+            bin.densityCorr_r.assign(chi_r + b * nb, chi_r + (b + 1) * nb);
+            if (unequal) { bin.n_tau = n_tau; bin.unequal_r.assign(unequal + (size_t)b * 3 * n_tau * nb, unequal + (size_t)(b + 1) * 3 * n_tau * nb); }
+            w.write_bin(bin);
+        }
+        return 0;
+    } catch (const std::exception& e) {
+        if (err && errlen > 0) { std::strncpy(err, e.what(), errlen - 1); err[errlen - 1] = 0; }
+        return -1;
+    }
+}
+// Reads a fp64 dataset back: ndims / dims (up to 8) / data (up to capacity doubles).  Returns the element count, or -1.
+long long dqmc_host_results_read(const char* file, const char* dataset, int* ndims, unsigned long long* dims, double* data, long long capacity,
+                                 char* err, int errlen) {
+    try {
+        std::vector<hdf5::hsize_t> d;
+        const std::vector<double> v = hdf5::read_array(file, dataset, &d);
+        if (ndims) *ndims = (int)d.size();
+        if (dims) for (size_t k = 0; k < d.size() && k < 8; ++k) dims[k] = d[k];
+        if (data) std::copy(v.begin(), v.begin() + std::min<long long>((long long)v.size(), capacity), data);
+        return (long long)v.size();
     } catch (const std::exception& e) {
         if (err && errlen > 0) { std::strncpy(err, e.what(), errlen - 1); err[errlen - 1] = 0; }
         return -1;

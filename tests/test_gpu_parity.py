@@ -555,3 +555,48 @@ def test_golden_vectors(hip, name):
         e.sweep_0_to_beta(z["perm_f"], z["k_f"], z["u_f"]); e.sweep_beta_to_0(z["perm_b"], z["k_b"], z["u_b"])
         assert (e.get_fields() == z["fields_after"]).all()
         assert np.abs(e.get_G() - z["G_after"]).max() <= float(z["tol"]) * max(1.0, np.abs(z["G_after"]).max())
+
+
+# ---- the main.cpp-shaped driver writes results/ in the reference's on-disk format -------------------
+def test_driver_writes_reference_results_layout(hip, tmp_path):
+    """dqmc_driver (dqmc_amd/host/main.cpp) on a 4x4 lattice with the unequal-time path on: results/info and
+    results/data_<rank>.h5 with /bin_k and /binK_k groups (include/measurementh5.h:277-362); the scalars in the file are the
+    bin averages the driver prints, densityCorr(k) sums back to chi_r, greenTau(r = 0, tau = 0) = 2 - <n>."""
+    import ctypes as C, re, subprocess
+    import dqmc_amd
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    driver = os.path.join(here, "dqmc_amd", "dqmc_driver")
+    assert os.path.exists(driver), "dqmc_driver missing: run make / __graft_entry__.build()"
+    ini = ("[Lattice]\nL1 = 4\nL2 = 4\n[hubbard]\nU = 4.0\nt = 1.0\nmu = -0.1\n[simulation]\nbeta = 2.0\nnt = 20\nn_therms = 5\nn_sweeps = 4\n"
+           "n_bins = 2\nn_stab = 10\nsymmetric = true\nisMeasureUnequalTime = true\n[ParallelTempering]\nenabled = false\nsweep_steps = 20\nbetas = 2.0\n")
+    (tmp_path / "parameters.in").write_text(ini)
+    out = subprocess.run([driver, "parameters.in", "0", "777", "3"], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "no HDF5 output" not in out.stderr, out.stderr
+    info = (tmp_path / "results" / "info").read_text()
+    assert "L1 4" in info and "n_orb 1" in info
+    path = str(tmp_path / "results" / "data_3.h5")
+    assert os.path.exists(path)
+    h = C.CDLL(dqmc_amd.HOST_LIB_PATH)
+    h.dqmc_host_results_read.restype = C.c_longlong
+    h.dqmc_host_results_read.argtypes = [C.c_char_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_char_p, C.c_int]
+    def read(ds):
+        nd = C.c_int(0); dims = (C.c_ulonglong * 8)(); err = C.create_string_buffer(256)
+        cnt = h.dqmc_host_results_read(path.encode(), ds.encode(), C.byref(nd), dims, None, 0, err, 256)
+        assert cnt >= 0, (ds, err.value)
+        data = np.empty(cnt); h.dqmc_host_results_read(path.encode(), ds.encode(), None, None, data.ctypes.data, cnt, err, 256)
+        return data.reshape([dims[k] for k in range(nd.value)])
+    printed = re.findall(r"bin (\d+) \((\d+) sweeps\): density ([-\d.eE+]+)\s+doubleOcc ([-\d.eE+]+)\s+swave ([-\d.eE+]+)", out.stdout)
+    assert len(printed) == 2, out.stdout
+    for b, (_, n, dens, docc, sw) in enumerate(printed):
+        assert int(n) == 4
+        assert abs(read(f"/bin_{b}/scalar/density")[0] - float(dens)) < 1e-7
+        assert abs(read(f"/bin_{b}/scalar/doubleOcc")[0] - float(docc)) < 1e-7
+        assert abs(read(f"/bin_{b}/scalar/swave")[0] - float(sw)) < 1e-7
+        chi_r = read(f"/bin_{b}/equaltime/densityCorr"); chi_k = read(f"/binK_{b}/equaltime/densityCorr")
+        assert chi_r.shape == (4, 4, 1) and chi_k.shape == (4, 4, 1, 2)
+        assert abs(chi_k[..., 0].sum() / 16.0 - chi_r[1, 1, 0]) < 1e-10           # inverse transform at r = 0 (dx_idx = L/2 - 1)
+        g = read(f"/bin_{b}/unequaltime/greenTau")
+        assert g.shape == (4, 4, 21) and read(f"/binK_{b}/unequaltime/currxxTau").shape == (4, 4, 21, 2)
+        # greenTau = Gt0_up + Gt0_dn (source/model.cpp:311), Gt0[0] = Gtt[0], <n> = (2/N) sum_i (1 - G_ii)  =>  greenTau(r = 0, tau = 0) = 2 - <n>
+        assert abs(g[1, 1, 0] - (2.0 - read(f"/bin_{b}/scalar/density")[0])) < 1e-9

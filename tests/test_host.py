@@ -107,3 +107,86 @@ def test_ini_reader(host):
     rc, _, msg = get(b"simulation", b"missing", 0); assert rc == -1 and "not found" in msg
     rc, _, msg = get(b"nosuch", b"nt", 0); assert rc == -1 and "Section" in msg
     rc, _, msg = get(b"simulation", b"name", 0); assert rc == -1 and "Cannot convert" in msg
+
+
+# ---- on-disk results in the reference's HDF5 layout (dqmc_amd/host/results_h5.hpp) ------------------
+def _h5_read(h, path, dataset):
+    h.dqmc_host_results_read.restype = C.c_longlong
+    h.dqmc_host_results_read.argtypes = [C.c_char_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_char_p, C.c_int]
+    nd = C.c_int(0); dims = (C.c_ulonglong * 8)(); err = C.create_string_buffer(256)
+    cnt = h.dqmc_host_results_read(path.encode(), dataset.encode(), C.byref(nd), dims, None, 0, err, 256)
+    assert cnt >= 0, err.value
+    data = np.empty(cnt, np.float64)
+    assert h.dqmc_host_results_read(path.encode(), dataset.encode(), None, None, data.ctypes.data, cnt, err, 256) == cnt
+    return data.reshape([dims[k] for k in range(nd.value)])
+
+
+def _chi_k_numpy(chi_r, L1, L2):
+    """transform::chi_r_to_chi_k (include/measurementh5.h:77-117) for the square lattice a1 = x, a2 = y:
+    chi_r[t, dx_idx + L1 * dy_idx] -> chi_k[kx, ky, t], k = (qx * 2pi / L1, qy * 2pi / L2), q = idx - L/2 + 1."""
+    n_tau = chi_r.shape[0]
+    r = chi_r.reshape(n_tau, L2, L1)                       # [t, y_idx, x_idx]
+    dx = np.arange(L1) - (L1 // 2 - 1); dy = np.arange(L2) - (L2 // 2 - 1)
+    kx = (np.arange(L1) - L1 // 2 + 1) * 2 * np.pi / L1; ky = (np.arange(L2) - L2 // 2 + 1) * 2 * np.pi / L2
+    wx = np.exp(-1j * np.outer(kx, dx)); wy = np.exp(-1j * np.outer(ky, dy))          # [kx, x], [ky, y]
+    return np.einsum("ax,by,tyx->abt", wx, wy, r)
+
+
+@pytest.mark.parametrize("L1,L2,nt", [(4, 4, 6), (6, 4, 5)])
+def test_results_file_has_the_reference_layout(host, tmp_path, L1, L2, nt):
+    """/bin_k/{scalar,equaltime,unequaltime} and /binK_k/{equaltime,unequaltime} with the reference's dataset names, dims and
+    element order (include/measurementh5.h:277-362, include/h5utils.h:9-119): C-order [dx][dy][tau] cubes, complex as a
+    trailing dimension of 2; the k-space data against an independent numpy evaluation of the transform."""
+    h = host
+    h.dqmc_host_results_write.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_char_p, C.c_int]
+    rng = np.random.default_rng(L1 * 100 + L2)
+    n_bins, n_tau, nb = 3, nt + 1, L1 * L2
+    scalars = rng.normal(size=(n_bins, 3)); chi = rng.normal(size=(n_bins, nb)); ut = rng.normal(size=(n_bins, 3, n_tau, nb))
+    err = C.create_string_buffer(256)
+    rc = h.dqmc_host_results_write(str(tmp_path).encode(), 5, L1, L2, n_bins, scalars.ctypes.data, chi.ctypes.data, ut.ctypes.data, n_tau, err, 256)
+    if rc != 0 and b"libhdf5 not found" in err.value:
+        pytest.skip("no libhdf5 on this machine")
+    assert rc == 0, err.value
+    path = str(tmp_path / "data_5.h5")
+    assert os.path.exists(path)
+    for b in range(n_bins):
+        for k, name in enumerate(("density", "doubleOcc", "swave")):
+            v = _h5_read(h, path, f"/bin_{b}/scalar/{name}")
+            assert v.shape == (1,) and v[0] == scalars[b, k]
+        d = _h5_read(h, path, f"/bin_{b}/equaltime/densityCorr")
+        assert d.shape == (L1, L2, 1)
+        np.testing.assert_array_equal(d[:, :, 0], chi[b].reshape(L2, L1).T)              # [dx_idx][dy_idx]
+        dk = _h5_read(h, path, f"/binK_{b}/equaltime/densityCorr")
+        assert dk.shape == (L1, L2, 1, 2)
+        ref = _chi_k_numpy(chi[b][None, :], L1, L2)
+        np.testing.assert_allclose(dk[..., 0] + 1j * dk[..., 1], ref, atol=1e-12)
+        for o, name in enumerate(("greenTau", "doublonTau", "currxxTau")):
+            d = _h5_read(h, path, f"/bin_{b}/unequaltime/{name}")
+            assert d.shape == (L1, L2, n_tau)
+            np.testing.assert_array_equal(d, ut[b, o].reshape(n_tau, L2, L1).transpose(2, 1, 0))
+            dk = _h5_read(h, path, f"/binK_{b}/unequaltime/{name}")
+            assert dk.shape == (L1, L2, n_tau, 2)
+            np.testing.assert_allclose(dk[..., 0] + 1j * dk[..., 1], _chi_k_numpy(ut[b, o], L1, L2), atol=1e-12)
+    # the file is a regular HDF5 file other tools can open: h5dump (shipped with the library) lists the same groups
+    import shutil, subprocess
+    h5dump = shutil.which("h5dump") or ("/opt/conda/bin/h5dump" if os.path.exists("/opt/conda/bin/h5dump") else None)
+    if h5dump:
+        out = subprocess.run([h5dump, "-n", path], capture_output=True, text=True, timeout=60)
+        assert out.returncode == 0, out.stderr
+        for g in ("/bin_0/scalar/density", "/bin_2/unequaltime/currxxTau", "/binK_1/equaltime/densityCorr", "/binK_2/unequaltime/greenTau"):
+            assert g in out.stdout
+
+
+def test_results_k_space_of_a_delta_is_flat(host, tmp_path):
+    """chi_r = delta at r = 0 transforms to chi_k = 1 for every k (known answer)."""
+    h = host
+    h.dqmc_host_results_write.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_char_p, C.c_int]
+    L1 = L2 = 6
+    chi = np.zeros((1, L1 * L2)); chi[0, (L1 // 2 - 1) + L1 * (L2 // 2 - 1)] = 1.0
+    scalars = np.zeros((1, 3)); err = C.create_string_buffer(256)
+    rc = h.dqmc_host_results_write(str(tmp_path).encode(), 0, L1, L2, 1, scalars.ctypes.data, chi.ctypes.data, None, 0, err, 256)
+    if rc != 0 and b"libhdf5 not found" in err.value:
+        pytest.skip("no libhdf5 on this machine")
+    assert rc == 0, err.value
+    dk = _h5_read(h, str(tmp_path / "data_0.h5"), "/binK_0/equaltime/densityCorr")
+    np.testing.assert_allclose(dk[..., 0], 1.0, atol=1e-14); np.testing.assert_allclose(dk[..., 1], 0.0, atol=1e-14)
