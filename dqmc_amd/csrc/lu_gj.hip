@@ -26,6 +26,7 @@
 // 8 us) instead of the 8 x (30 + 18 + 7) us of lu_blocked.hip plus a ~200 us substitution.
 #include "common.h"
 #include "wave.h"
+#include <cstdlib>
 
 namespace dq {
 
@@ -187,6 +188,140 @@ __global__ __launch_bounds__(64) void gj_panel_kernel(CMat Am, int* rowpos_p, lo
     }
 }
 
+// ---- multi-wave panel: one row per lane, W = ceil(n / 64) waves (one per SIMD) ------------------------------------------------
+// The single-wave kernel above is bound by instruction issue (one wave, ~12 k instructions).  Here every wave owns 64 rows, so a
+// step costs a quarter of the FMAs per wave, at the price of one workgroup barrier per step: each wave finds its own best row,
+// and its candidate lane publishes {key, lane} and the row's live part (columns >= J) into the wave's LDS slot BEFORE the global
+// winner is known; after the barrier every wave reads the W keys, picks the winner (largest |a|, lowest wave on ties) and reads the
+// pivot row from the winner's slot.  Slots are double-buffered on the parity of J (a wave can be at most one step ahead).
+template <int J>
+__device__ __forceinline__ void gj_step_mw(double (&a)[GJ_NB], bool& live, int& mypos, int& myperm, bool& singular, int lane, int wave, int nw, int k0,
+                                           double (*slot_row)[4][GJ_NB + 2], unsigned long long (*slot_key)[4]) {
+    constexpr int PAR = J & 1;
+    constexpr int C0 = J & ~1;
+    // every lane's reciprocal of its own candidate element, off the critical path (dgetf2 scales by the reciprocal pivot as
+    // well): v_rcp_f64 + two Newton steps; the winner's value travels with its row
+    double rme = __builtin_amdgcn_rcp(a[J]);
+    rme = fma(fma(-a[J], rme, 1.0), rme, rme);
+    rme = fma(fma(-a[J], rme, 1.0), rme, rme);
+    const unsigned long long key = live ? ((unsigned long long)__double_as_longlong(fabs(a[J])) | 1ULL) : 0ULL;
+    const unsigned hi = (unsigned)(key >> 32), lo = (unsigned)key;
+    const unsigned m1 = wave_max_u32(hi);
+    const unsigned m2 = wave_max_u32(hi == m1 ? lo : 0u);
+    const unsigned long long winners = __ballot(hi == m1 && lo == m2 && live);
+    const int cl = winners ? (int)__builtin_ctzll(winners) : 0;
+    if (lane == cl) {                                     // this wave's candidate
+#pragma unroll
+        for (int c = C0; c < GJ_NB; c += 2) *reinterpret_cast<double2*>(&slot_row[PAR][wave][c]) = make_double2(a[c], a[c + 1]);
+        slot_row[PAR][wave][GJ_NB] = rme;
+        // key: |a| with its low 9 bits replaced by {non-empty marker, lane}; waves compare bits 8 and up (44 mantissa bits)
+        slot_key[PAR][wave] = winners ? ((((unsigned long long)m1 << 32) | m2) & ~0xFFULL) | (unsigned long long)cl | 0x100ULL : 0ULL;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    unsigned long long best = slot_key[PAR][0]; int pw = 0;
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+        if (w < nw) { const unsigned long long o = slot_key[PAR][w]; if ((o >> 8) > (best >> 8)) { best = o; pw = w; } }
+    }
+    const int pl = (int)(best & 0xFFULL);
+    double prow[GJ_NB - C0];
+#pragma unroll
+    for (int c = C0; c < GJ_NB; c += 2) { const double2 v = *reinterpret_cast<const double2*>(&slot_row[PAR][pw][c]); prow[c - C0] = v.x; prow[c + 1 - C0] = v.y; }
+    const double r = slot_row[PAR][pw][GJ_NB];
+    if (lane == J && wave == 0) myperm = pl + 64 * pw;
+    if (wave == pw && lane == pl) { live = false; mypos = k0 + J; }
+    singular = singular || !(fabs(prow[J - C0]) > 0.0);
+    // branch-free: dead rows (earlier pivots, rows >= n) run the FMAs with l = 0, so the next step's pivot search can be
+    // scheduled into them
+    const double l = live ? a[J] * r : 0.0;
+    a[J] = live ? l : a[J];
+#pragma unroll
+    for (int c = J + 1; c < GJ_NB; ++c) a[c] = fma(-l, prow[c - C0], a[c]);
+}
+template <int J>
+struct GjStepsMW {
+    static __device__ __forceinline__ void run(double (&a)[GJ_NB], bool& live, int& mypos, int& myperm, bool& singular, int lane, int wave, int nw, int nbw, int k0,
+                                               double (*slot_row)[4][GJ_NB + 2], unsigned long long (*slot_key)[4]) {
+        if (J < nbw) gj_step_mw<J>(a, live, mypos, myperm, singular, lane, wave, nw, k0, slot_row, slot_key);      // workgroup-uniform
+        GjStepsMW<J + 1>::run(a, live, mypos, myperm, singular, lane, wave, nw, nbw, k0, slot_row, slot_key);
+    }
+};
+template <>
+struct GjStepsMW<GJ_NB> {
+    static __device__ __forceinline__ void run(double (&)[GJ_NB], bool&, int&, int&, bool&, int, int, int, int, int, double (*)[4][GJ_NB + 2], unsigned long long (*)[4]) {}
+};
+
+__global__ __launch_bounds__(256) void gj_panel_mw_kernel(CMat Am, int* rowpos_p, long rowpos_stride, int* perm_p, long perm_stride, double* tinv_p,
+                                                          double* logabsdet, int accumulate, int* info, int n, int k0) {
+    __shared__ __attribute__((aligned(16))) double LU[GJ_NB][GJ_NB];
+    __shared__ __attribute__((aligned(16))) double slot_row[2][4][GJ_NB + 2];      // row | reciprocal of its pivot element
+    __shared__ unsigned long long slot_key[2][4];
+    __shared__ int s_sing;
+    const int chain = blockIdx.y;
+    const double* __restrict__ A = Am.at(chain);
+    int* rowpos = rowpos_p + (long)chain * rowpos_stride;
+    int* perm = perm_p + (long)chain * perm_stride;
+    double* tinv = tinv_p + (long)chain * 2 * GJ_NB * GJ_NB;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, nw = blockDim.x >> 6;
+    const int nbw = min(GJ_NB, n - k0);
+    const int r = t;
+    bool live = r < n && (k0 == 0 ? true : rowpos[r] < 0);
+    int mypos = -1, myperm = 0; bool singular = false;
+    double a[GJ_NB];
+#pragma unroll
+    for (int c = 0; c < GJ_NB; ++c) a[c] = (live && c < nbw) ? A[r + (long)n * (k0 + c)] : 0.0;
+    for (int e = t; e < GJ_NB * GJ_NB; e += blockDim.x) (&LU[0][0])[e] = ((e >> 5) == (e & 31)) ? 1.0 : 0.0;   // identity padding for nbw < 32
+    if (t == 0) s_sing = 0;
+
+    GjStepsMW<0>::run(a, live, mypos, myperm, singular, lane, wave, nw, nbw, k0, slot_row, slot_key);
+
+    __syncthreads();                                     // identity fill done everywhere before the pivot rows overwrite theirs
+    if (r < n) { if (k0 == 0) rowpos[r] = mypos; else if (mypos >= 0) rowpos[r] = mypos; }
+    if (mypos >= 0) {
+        double* dst = &LU[mypos - k0][0];
+#pragma unroll
+        for (int c = 0; c < GJ_NB; c += 2) *reinterpret_cast<double2*>(dst + c) = make_double2(a[c], a[c + 1]);
+    }
+    if (wave == 0 && lane < nbw) perm[k0 + lane] = myperm;
+    if (singular && lane == 0) s_sing = 1;
+    __syncthreads();
+    for (int e = t; e < GJ_NB * GJ_NB; e += blockDim.x) tinv[e] = (&LU[0][0])[e];
+    if (wave == 0) {
+        {                                                // log|det P11| and singularity check
+            const double pv = lane < nbw ? fabs(LU[lane][lane]) : 1.0;
+            const double ls = wave_sum(log(pv));
+            if (lane == 0) {
+                if (logabsdet) logabsdet[chain] = ((accumulate || k0 > 0) ? logabsdet[chain] : 0.0) + ls;
+                if (info && (s_sing || !(ls == ls))) atomicOr(info, 1);
+            }
+        }
+        // the four 16 x 16 triangular inverses, one column per lane (see gj_panel_kernel)
+        const int blk = lane >> 4, c = lane & 15;
+        const bool up = blk >= 2;
+        const int base = (blk & 1) * 16;
+        const double* T0 = &LU[0][0] + (up ? (base + 15) * 33 : base * 33);
+        const int sg = up ? -1 : 1;
+        const int cc = up ? 15 - c : c;
+        double x[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            double s0 = (j == cc) ? 1.0 : 0.0, s1 = 0.0;
+#pragma unroll
+            for (int m = 0; m < j; ++m) {
+                const double tt = T0[sg * (j * 32 + m)];
+                if (m & 1) s1 = fma(-tt, x[m], s1); else s0 = fma(-tt, x[m], s0);
+            }
+            const double s = s0 + s1;
+            x[j] = up ? s / T0[sg * (j * 33)] : s;
+        }
+        double* out = tinv + GJ_NB * GJ_NB + 256 * blk + 16 * c;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) out[up ? 15 - j : j] = x[j];
+    }
+}
+
 // MFMA operand convention (v_mfma_f64_16x16x4_f64, lane = (r16, kk) = (lane & 15, lane >> 4)):
 //   mfma(a, b, acc): a = A[row r16][k kk], b = B[k kk][col r16], acc[reg] = D[row kk + 4 reg][col r16].
 // A D tile therefore feeds the next product as its B operand directly: acc[reg] of lane (c, kk) is row k = kk + 4 reg
@@ -317,7 +452,9 @@ int launch_gj_solve(Mat A, Mat B, Mat X, Mat SA, double* tinv, int* perm, long p
     if (n > 256) { set_error("gj_solve supports n <= 256"); return -1; }
     for (int k0 = 0; k0 < n; k0 += GJ_NB) {
         const dim3 pg(1, n_chains);
-        if (n <= 64) hipLaunchKernelGGL((gj_panel_kernel<1>), pg, dim3(64), 0, s, CMat(A), rowpos, rowpos_stride, perm, perm_stride, tinv, logabsdet, accumulate_logdet, info, n, k0);
+        static const bool one_wave = getenv("DQMC_GJ_PANEL_1W") != nullptr;      // A/B switch: the single-wave panel
+        if (!one_wave && n > 64) hipLaunchKernelGGL(gj_panel_mw_kernel, pg, dim3(((n + 63) / 64) * 64), 0, s, CMat(A), rowpos, rowpos_stride, perm, perm_stride, tinv, logabsdet, accumulate_logdet, info, n, k0);
+        else if (n <= 64) hipLaunchKernelGGL((gj_panel_kernel<1>), pg, dim3(64), 0, s, CMat(A), rowpos, rowpos_stride, perm, perm_stride, tinv, logabsdet, accumulate_logdet, info, n, k0);
         else if (n <= 128) hipLaunchKernelGGL((gj_panel_kernel<2>), pg, dim3(64), 0, s, CMat(A), rowpos, rowpos_stride, perm, perm_stride, tinv, logabsdet, accumulate_logdet, info, n, k0);
         else hipLaunchKernelGGL((gj_panel_kernel<4>), pg, dim3(64), 0, s, CMat(A), rowpos, rowpos_stride, perm, perm_stride, tinv, logabsdet, accumulate_logdet, info, n, k0);
         const int nbw = n - k0 < GJ_NB ? n - k0 : GJ_NB;
