@@ -149,6 +149,16 @@ def main():
             "gemm_chain": {"algorithmic_gemms_per_sweep": g_alg, "flop_per_sweep": g_alg * 2.0 * n ** 3,
                            "peak_tflops": FP64_MFMA_PEAK_TFLOPS},
         }
+        # GEMM chain in situ: 200 wraps (B G B^-1 then B^-1 G B: 4 GEMMs of 2N^3 flop, G returns to itself up to rounding) enqueued
+        # back to back on the engine's stream, the way a sweep issues them; wall time / 800 = time per GEMM including its launch gap
+        n_pairs = 200
+        eng.sync(); tg0 = time.perf_counter()
+        for _ in range(n_pairs):
+            eng.wrap_forward(0); eng.wrap_backward(0)
+        eng.sync(); tg = (time.perf_counter() - tg0) / (4 * n_pairs)
+        gflop = 2.0 * n ** 3 * C
+        out["gemm_chain"].update({"avg_gemm_us": tg * 1e6, "achieved_tflops": gflop / tg / 1e12, "frac": gflop / tg / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                                  "bound": "mfma", "note": "one 256^3 GEMM is launch/latency bound; the batched engines run the same chain at 41 TFLOP/s (DESIGN.md 4)"})
         if world == 1 and args.batched_chains > 1 and C == 1:
             # throughput mode: the same kernels advance B independent chains per launch (blockIdx.y = chain), optionally spread
             # over E engines (own HIP stream and host thread each).  The random streams are drawn before the clock starts: with
