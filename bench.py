@@ -35,13 +35,44 @@ def gen_streams(model, rng, C):
     return tuple(np.stack([s[k] for s in st]) for k in range(3))
 
 
-def cpu_baseline(model, seed, budget_s=20.0):
+def parity_vs_cpu(model, orc, lib, device, config):
+    """max|dG| of the HIP engine against the CPU oracle on identical fields and random streams (the metric's second half):
+    thermalised fixture fields when the config has one (the 1e-10 target is meaningful there), init + one sweep."""
+    gold = os.path.join(ROOT, "tests", "golden", f"{config}_therm.npz")
+    fields = np.load(gold)["fields"] if os.path.exists(gold) else model.random_fields(4711)
+    out = {"fields": "thermalised fixture" if os.path.exists(gold) else "iid random"}
+    g = model.engine(lib, device=device); c = model.engine(orc)
+    try:
+        for e in (g, c):
+            e.set_fields(fields); e.init()
+        Gg, Gc = g.get_G(), c.get_G()
+        out["max_abs_dG_init"] = float(np.abs(Gg - Gc).max()); out["max_abs_G"] = float(np.abs(Gc).max())
+        rng = np.random.default_rng(99)
+        s1, s2 = model.random_stream(rng), model.random_stream(rng)
+        for e in (g, c):
+            e.sweep_0_to_beta(*s1); e.sweep_beta_to_0(*s2)
+        Gg, Gc = g.get_G(), c.get_G()
+        out["max_abs_dG_after_sweep"] = float(np.abs(Gg - Gc).max())
+        out["max_abs_G_after_sweep"] = float(np.abs(Gc).max())
+        out["fields_identical_after_sweep"] = bool(np.array_equal(g.get_fields(), c.get_fields()))
+        out["tolerance"] = "1e-10 * max(1, max|G|) (tests/test_gpu_parity.py)"
+        out["within_tolerance"] = bool(out["max_abs_dG_init"] <= 1e-10 * max(1.0, out["max_abs_G"])
+                                       and out["max_abs_dG_after_sweep"] <= 1e-10 * max(1.0, out["max_abs_G_after_sweep"]))
+    finally:
+        g.close(); c.close()
+    return out
+
+
+def cpu_baseline(model, seed, budget_s=20.0, lib=None, device=0, config="cfg3"):
     """The oracle (a port: the reference cannot be built here) timed on one host
     core on a bounded sample of the same workload."""
     from oracle import oracle
     orc = oracle()
     kind_blas = "lapack" if orc.set_backend("lapack") else "builtin"
+    parity = None
     try:
+        if lib is not None:
+            parity = parity_vs_cpu(model, orc, lib, device, config)
         e = model.engine(orc); e.set_fields(model.random_fields(seed)); e.init()
         rng = np.random.default_rng(seed)
         e.sweep_0_to_beta(*model.random_stream(rng)); e.sweep_beta_to_0(*model.random_stream(rng))   # warm-up sweep
@@ -54,8 +85,11 @@ def cpu_baseline(model, seed, budget_s=20.0):
         backend = orc.backend()
     finally:
         orc.set_backend("builtin")
-    return {"value": n / dt, "unit": "sweeps/s", "cores": 1, "kind": "port",
-            "sample": f"{n} sweeps of 1 chain after 1 warm-up sweep, single thread, {backend}"}
+    out = {"value": n / dt, "unit": "sweeps/s", "cores": 1, "kind": "port",
+           "sample": f"{n} sweeps of 1 chain after 1 warm-up sweep, single thread, {backend}"}
+    if parity is not None:
+        out["max_dG_vs_cpu"] = parity
+    return out
 
 
 def main():
@@ -189,7 +223,7 @@ def main():
                               "note": "aggregate over independent chains sharing kernel launches; not the headline config"}
             for (ee, _, _) in engs: ee.close()
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(model, 12345, args.cpu_budget)
+            out["cpu_baseline"] = cpu_baseline(model, 12345, args.cpu_budget, lib, local_rank, args.config)
         print(json.dumps(out), flush=True)
     eng.close()
     finalize(d)
