@@ -231,11 +231,14 @@ __device__ __forceinline__ void gj_step_mw(double (&a)[GJ_NB], bool& live, int& 
 #if defined(GJ_EXP) && (GJ_EXP & 16)
     unsigned long long best = (unsigned long long)(J & 63); int pw = J & 3;
 #else
-    unsigned long long best = slot_key[PAR][0]; int pw = 0;
-#pragma unroll
-    for (int w = 1; w < 4; ++w) {
-        if (w < nw) { const unsigned long long o = slot_key[PAR][w]; if ((o >> 8) > (best >> 8)) { best = o; pw = w; } }
-    }
+    // all four keys in ONE LDS round trip (slots of absent waves stay 0 = "no candidate"): reading them under `w < nw` branches
+    // made each key its own dependent round trip, ~450 clk per step
+    const ulonglong2 k01 = *reinterpret_cast<const ulonglong2*>(&slot_key[PAR][0]);
+    const ulonglong2 k23 = *reinterpret_cast<const ulonglong2*>(&slot_key[PAR][2]);
+    unsigned long long best = k01.x; int pw = 0;
+    if ((k01.y >> 8) > (best >> 8)) { best = k01.y; pw = 1; }
+    if ((k23.x >> 8) > (best >> 8)) { best = k23.x; pw = 2; }
+    if ((k23.y >> 8) > (best >> 8)) { best = k23.y; pw = 3; }
 #endif
     const int pl = (int)(best & 0xFFULL);
     double prow[GJ_NB - C0];
@@ -277,7 +280,7 @@ __global__ __launch_bounds__(256) void gj_panel_mw_kernel(CMat Am, int* rowpos_p
                                                           double* logabsdet, int accumulate, int* info, int n, int k0) {
     __shared__ __attribute__((aligned(16))) double LU[GJ_NB][GJ_NB];
     __shared__ __attribute__((aligned(16))) double slot_row[2][4][GJ_NB + 2];      // row | reciprocal of its pivot element
-    __shared__ unsigned long long slot_key[2][4];
+    __shared__ __attribute__((aligned(16))) unsigned long long slot_key[2][4];
     __shared__ int s_sing;
     const int chain = blockIdx.y;
     const double* __restrict__ A = Am.at(chain);
@@ -294,6 +297,8 @@ __global__ __launch_bounds__(256) void gj_panel_mw_kernel(CMat Am, int* rowpos_p
     for (int c = 0; c < GJ_NB; ++c) a[c] = (live && c < nbw) ? A[r + (long)n * (k0 + c)] : 0.0;
     for (int e = t; e < GJ_NB * GJ_NB; e += blockDim.x) (&LU[0][0])[e] = ((e >> 5) == (e & 31)) ? 1.0 : 0.0;   // identity padding for nbw < 32
     if (t == 0) s_sing = 0;
+    if (t < 8) (&slot_key[0][0])[t] = 0ULL;               // waves that do not exist never publish: their keys stay "no candidate"
+    __syncthreads();
 
     GjStepsMW<0>::run(a, live, mypos, myperm, singular, lane, wave, nw, nbw, k0, slot_row, slot_key);
 
