@@ -600,3 +600,20 @@ def test_driver_writes_reference_results_layout(hip, tmp_path):
         assert g.shape == (4, 4, 21) and read(f"/binK_{b}/unequaltime/currxxTau").shape == (4, 4, 21, 2)
         # greenTau = Gt0_up + Gt0_dn (source/model.cpp:311), Gt0[0] = Gtt[0], <n> = (2/N) sum_i (1 - G_ii)  =>  greenTau(r = 0, tau = 0) = 2 - <n>
         assert abs(g[1, 1, 0] - (2.0 - read(f"/bin_{b}/scalar/density")[0])) < 1e-9
+
+
+@pytest.mark.parametrize("L1,L2", [(10, 10), (12, 12), (16, 8), (9, 8)])
+def test_mid_sizes_between_the_named_configs(hip, orc, L1, L2):
+    """64 < N < 256 (N = 100, 144, 128, 72): two / three-wave Gauss-Jordan panels with a partial last panel, partial MFMA tiles in the
+    update, the classic formq for N not in {16, 32, 64, 128, 256}, QRCP padding columns."""
+    m = HubbardModel(L1=L1, L2=L2, U=4.0, beta=2.0, nt=20, n_stab=10); f = m.random_fields(11)
+    e = m.engine(hip); e.set_fields(f); e.init(); o = m.engine(orc); o.set_fields(f); o.init()
+    assert close(e.get_G(), o.get_G())
+    assert abs(e.get_logdet() - o.get_logdet()) < 1e-9 * max(1.0, abs(o.get_logdet()))
+    rng = np.random.default_rng(5)
+    s1, s2 = m.random_stream(rng), m.random_stream(rng)
+    e.sweep_0_to_beta(*s1); o.sweep_0_to_beta(*s1)
+    assert (e.get_fields() == o.get_fields()).all() and close(e.get_G(), o.get_G())
+    e.sweep_beta_to_0(*s2); o.sweep_beta_to_0(*s2)
+    assert (e.get_fields() == o.get_fields()).all() and close(e.get_G(), o.get_G())
+    assert e.stats().n_accepted == o.stats().n_accepted
