@@ -36,19 +36,6 @@ using d4 = __attribute__((ext_vector_type(4))) double;
 
 __device__ __forceinline__ void lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
-// max over the 64 lanes of a 32-bit unsigned key (wave-uniform result): one v_max_u32 with a DPP operand per stage
-__device__ __forceinline__ unsigned wave_max_u32(unsigned k) {
-#define DQ_MAX32(CTRL, MASK) { const unsigned o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)k, CTRL, MASK, 0xf, false); k = o > k ? o : k; }
-    DQ_MAX32(0xB1, 0xf)        // quad_perm [1,0,3,2]
-    DQ_MAX32(0x4E, 0xf)        // quad_perm [2,3,0,1]
-    DQ_MAX32(0x141, 0xf)       // row_half_mirror
-    DQ_MAX32(0x140, 0xf)       // row_mirror
-    DQ_MAX32(0x142, 0xa)       // row_bcast:15
-    DQ_MAX32(0x143, 0xc)       // row_bcast:31
-#undef DQ_MAX32
-    return (unsigned)__builtin_amdgcn_readlane((int)k, 63);
-}
-
 // One elimination step of the panel, J a compile-time constant so that every register index is static (a rolled
 // step loop would put the panel into scratch).  No LDS and no memory traffic: the pivot search is a per-lane max
 // over the lane's rows, two 32-bit DPP wave maxima (high word of |a|, then low word among the lanes that tie) and a

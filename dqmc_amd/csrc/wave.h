@@ -50,25 +50,28 @@ __device__ __forceinline__ double wave_sum_shfl(double x) {
     return x;
 }
 
-// max over 64 lanes of an unsigned 64-bit key, wave-uniform result
+// max over the 64 lanes of a 32-bit unsigned key (wave-uniform result): one v_max_u32 with a DPP operand per stage
+// (the compiler folds update_dpp + max into v_max_u32_dpp; lanes a row mask disables keep their own value)
+__device__ __forceinline__ unsigned wave_max_u32(unsigned k) {
+#define DQ_MAX32(CTRL, MASK) { const unsigned o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)k, CTRL, MASK, 0xf, false); k = o > k ? o : k; }
+    DQ_MAX32(0xB1, 0xf)        // quad_perm [1,0,3,2]
+    DQ_MAX32(0x4E, 0xf)        // quad_perm [2,3,0,1]
+    DQ_MAX32(0x141, 0xf)       // row_half_mirror
+    DQ_MAX32(0x140, 0xf)       // row_mirror
+    DQ_MAX32(0x142, 0xa)       // row_bcast:15
+    DQ_MAX32(0x143, 0xc)       // row_bcast:31
+#undef DQ_MAX32
+    return (unsigned)__builtin_amdgcn_readlane((int)k, 63);
+}
+
+// max over 64 lanes of an unsigned 64-bit key, wave-uniform result: the high words first, then the low words of the lanes that
+// tie on the high word -- the lexicographic maximum, i.e. exactly the 64-bit maximum, in 12 single-instruction DPP stages (a
+// 64-bit compare-and-select chain needs five instructions per stage)
 __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long k) {
-#define DQ_MAXSTEP(CTRL, MASK)                                                                             \
-    {                                                                                                      \
-        const int lo = __builtin_amdgcn_update_dpp(0, (int)(k & 0xffffffffULL), CTRL, MASK, 0xf, false);   \
-        const int hi = __builtin_amdgcn_update_dpp(0, (int)(k >> 32), CTRL, MASK, 0xf, false);             \
-        const unsigned long long o = ((unsigned long long)(unsigned int)hi << 32) | (unsigned int)lo;      \
-        k = o > k ? o : k;                                                                                 \
-    }
-    DQ_MAXSTEP(0xB1, 0xf)
-    DQ_MAXSTEP(0x4E, 0xf)
-    DQ_MAXSTEP(0x141, 0xf)
-    DQ_MAXSTEP(0x140, 0xf)
-    DQ_MAXSTEP(0x142, 0xa)
-    DQ_MAXSTEP(0x143, 0xc)
-#undef DQ_MAXSTEP
-    const int lo = __builtin_amdgcn_readlane((int)(k & 0xffffffffULL), 63);
-    const int hi = __builtin_amdgcn_readlane((int)(k >> 32), 63);
-    return ((unsigned long long)(unsigned int)hi << 32) | (unsigned int)lo;
+    const unsigned hi = (unsigned)(k >> 32), lo = (unsigned)k;
+    const unsigned m1 = wave_max_u32(hi);
+    const unsigned m2 = wave_max_u32(hi == m1 ? lo : 0u);
+    return ((unsigned long long)m1 << 32) | m2;
 }
 
 }  // namespace dq
