@@ -261,100 +261,6 @@ int launch_lu(Mat A, int* perm, long perm_stride, double* logabsdet, int accumul
     return launch_lu_nr<16>(A, perm, perm_stride, logabsdet, accumulate_logdet, info, n, n_chains, s);
 }
 
-// X = R^-1 diag(dg) for the R of ONE to_LDR result (mode 2 of lu_solve_kernel), n a multiple of 16, n <= 256, few chains:
-// block back substitution on the matrix cores instead of 256 dependent substitution steps per column.
-//   R = R1 Pi^T, R1 upper triangular (column perm[j] of R is column j of R1)  =>  X = Pi R1^-1 diag(dg):
-//   row perm[j] of X is row j of X' = R1^-1 diag(dg), and X' is upper triangular.
-// One workgroup per block J of 16 columns.  Phase 0 (4 waves): the diagonal 16 x 16 blocks of R1 go to LDS and are inverted, one
-// column per lane (back substitution run as a forward recurrence on the index-reversed block).  Phase 1 (wave 0): for row blocks
-// I = J .. 0:  X'_IJ = R_II^-1 (D_J [I == J] - sum_{I < K <= J} R_IK X'_KJ); a D tile of the MFMA is the B operand of the next
-// product as it is, finished X' tiles are parked in LDS, and all R_IK operands of a row block are in flight before its first
-// MFMA.  Waves 1..3 meanwhile write the zero rows below the diagonal block.
-__global__ __launch_bounds__(256) void tri_solve_blocked_kernel(CMat Rm, const int* perm_p, long perm_stride, Mat Xm, CVec dg, int n) {
-    using d4 = __attribute__((ext_vector_type(4))) double;
-    __shared__ double raw[16][256];                      // diagonal blocks of R1, raw[I][r + 16 s] = R1[16 I + r][16 I + s]
-    __shared__ double dinv[16][256];                     // their inverses, column-major
-    __shared__ double xs[16][256];                       // X'_KJ tiles in the MFMA D layout: xs[K][64 reg + lane]
-    __shared__ int sperm[256];
-    const int chain = blockIdx.y, J = blockIdx.x;
-    const double* __restrict__ R = Rm.at(chain);
-    const int* __restrict__ perm = perm_p + (long)chain * perm_stride;
-    double* __restrict__ X = Xm.at(chain);
-    const int t = threadIdx.x, lane = t & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int nb = n >> 4;
-    if (t < n) sperm[t] = perm[t];
-    __syncthreads();
-    {                                                    // phase 0a: stage the diagonal blocks I <= J
-        const int r = t & 15, sc = t >> 4;
-#pragma unroll
-        for (int I = 0; I < 16; ++I)
-            if (I <= J) raw[I][t] = (sc >= r) ? R[(16 * I + r) + (long)n * sperm[16 * I + sc]] : 0.0;
-    }
-    __syncthreads();
-    {                                                    // phase 0b: invert block I = 4 wave + (lane >> 4), column c = lane & 15
-        const int I = 4 * wave + (lane >> 4), c = lane & 15;
-        if (I <= J) {
-            const double* T0 = &raw[I][255];             // T'[j][m] = U[15 - j][15 - m] = raw[I][255 - (j + 16 m)]
-            const int cc = 15 - c;
-            double x[16];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                double s0 = (j == cc) ? 1.0 : 0.0, s1 = 0.0;
-#pragma unroll
-                for (int m = 0; m < j; ++m) {
-                    const double tt = T0[-(j + 16 * m)];
-                    if (m & 1) s1 = fma(-tt, x[m], s1); else s0 = fma(-tt, x[m], s0);
-                }
-                x[j] = (s0 + s1) / T0[-(17 * j)];
-            }
-#pragma unroll
-            for (int j = 0; j < 16; ++j) dinv[I][(15 - j) + 16 * c] = x[j];
-        }
-    }
-    __syncthreads();
-    const int r16 = lane & 15, kk = lane >> 4;
-    const int col = 16 * J + r16;
-    if (wave != 0) {                                     // rows of row blocks I > J are zero in this column block
-        for (int e = t - 64; e < 16 * (nb - 1 - J) * 16; e += 192) {
-            const int rr = 16 * (J + 1) + (e >> 4), cc2 = 16 * J + (e & 15);
-            X[sperm[rr] + (long)n * cc2] = 0.0;
-        }
-        return;
-    }
-    const double dgc = dg.at(chain)[col];
-    for (int I = J; I >= 0; --I) {
-        // operands -R1[16 I + r16][16 K + 4 s + kk] of every K in (I, J], all in flight before the first MFMA
-        double a[16][4];
-#pragma unroll
-        for (int K = 0; K < 16; ++K) {
-            if (K > I && K <= J) {                       // wave-uniform
-#pragma unroll
-                for (int s = 0; s < 4; ++s) a[K][s] = -R[(16 * I + r16) + (long)n * sperm[16 * K + 4 * s + kk]];
-            }
-        }
-        d4 acc;
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) acc[reg] = (I == J && kk + 4 * reg == r16) ? dgc : 0.0;
-#pragma unroll
-        for (int K = 0; K < 16; ++K) {
-            if (K > I && K <= J) {
-#pragma unroll
-                for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[K][s], xs[K][64 * s + lane], acc, 0, 0, 0);
-            }
-        }
-        d4 res = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int s = 0; s < 4; ++s) res = __builtin_amdgcn_mfma_f64_16x16x4f64(dinv[I][r16 + 16 * (4 * s + kk)], acc[s], res, 0, 0, 0);
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            xs[I][64 * reg + lane] = res[reg];
-            X[sperm[16 * I + kk + 4 * reg] + (long)n * col] = res[reg];
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the tile is in LDS before the next row block reads it (same wave: no barrier)
-    }
-}
-
 template <int NR>
 static int launch_solve_nr(CMat LU, const int* perm, long ps, Mat X, CVec dg, int mode, int n, int n_chains, hipStream_t s) {
     if (n_chains <= 4) hipLaunchKernelGGL((lu_solve_kernel<NR, 1>), dim3((n + 3) / 4, n_chains), dim3(256), 0, s, LU, perm, ps, X, dg, mode, n);
@@ -364,12 +270,6 @@ static int launch_solve_nr(CMat LU, const int* perm, long ps, Mat X, CVec dg, in
 }
 int launch_lu_solve(CMat LU, const int* perm, long perm_stride, Mat X, CVec dg, int mode, int n, int n_chains, hipStream_t s) {
     if (n > 1024) { set_error("LU solve kernel supports n <= 1024"); return -1; }
-    static const bool tri_classic = getenv("DQMC_TRI_CLASSIC") != nullptr;      // A/B switch: per-column substitution for X = R^-1 D as well
-    if (mode == 2 && !tri_classic && n % 16 == 0 && n <= 256 && n_chains <= 8) {
-        hipLaunchKernelGGL(tri_solve_blocked_kernel, dim3(n / 16, n_chains), dim3(256), 0, s, LU, perm, perm_stride, X, dg, n);
-        DQ_HIP(hipGetLastError());
-        return 0;
-    }
     if (n <= 64) return launch_solve_nr<1>(LU, perm, perm_stride, X, dg, mode, n, n_chains, s);
     if (n <= 128) return launch_solve_nr<2>(LU, perm, perm_stride, X, dg, mode, n, n_chains, s);
     if (n <= 256) return launch_solve_nr<4>(LU, perm, perm_stride, X, dg, mode, n, n_chains, s);
