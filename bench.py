@@ -83,10 +83,36 @@ def cpu_baseline(model, seed, budget_s=20.0, lib=None, device=0, config="cfg3"):
             if dt > budget_s or n >= 50:
                 break
         backend = orc.backend()
+        # the reference runs one Markov chain per MPI rank / host core (source/main.cpp:30-37): the same oracle on min(nproc, 8) cores at
+        # once, one chain per thread (the library calls release the GIL, MKL is sequential) -- SURVEY.md 8(d)
+        import threading
+        K = max(1, min(8, os.cpu_count() or 1))
+        counts = [0] * K; times = [0.0] * K
+        def chain(i):
+            ei = model.engine(orc); ei.set_fields(model.random_fields(seed + 1 + i)); ei.init()
+            ri = np.random.default_rng(seed + 1 + i)
+            ei.sweep_0_to_beta(*model.random_stream(ri)); ei.sweep_beta_to_0(*model.random_stream(ri))
+            t_0 = time.perf_counter()
+            while True:
+                ei.sweep_0_to_beta(*model.random_stream(ri)); ei.sweep_beta_to_0(*model.random_stream(ri)); counts[i] += 1
+                times[i] = time.perf_counter() - t_0
+                if times[i] > 0.5 * budget_s or counts[i] >= 50:
+                    break
+            ei.close()
+        multi = None
+        if K > 1 and budget_s > 0:
+            th = [threading.Thread(target=chain, args=(i,)) for i in range(K)]
+            for t_ in th: t_.start()
+            for t_ in th: t_.join()
+            multi = {"cores": K, "aggregate": sum(c / t_ for c, t_ in zip(counts, times) if t_ > 0), "unit": "sweeps/s",
+                     "per_chain": float(np.mean([c / t_ for c, t_ in zip(counts, times) if t_ > 0])),
+                     "sample": f"{K} independent chains, one per thread, {sum(counts)} sweeps in total"}
     finally:
         orc.set_backend("builtin")
     out = {"value": n / dt, "unit": "sweeps/s", "cores": 1, "kind": "port",
            "sample": f"{n} sweeps of 1 chain after 1 warm-up sweep, single thread, {backend}"}
+    if multi is not None:
+        out["all_cores"] = multi
     if parity is not None:
         out["max_dG_vs_cpu"] = parity
     return out
