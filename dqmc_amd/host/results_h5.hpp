@@ -97,6 +97,7 @@ struct Api {
         DQ_H5SYM(H5Dget_space); DQ_H5SYM(H5Sget_simple_extent_ndims); DQ_H5SYM(H5Sget_simple_extent_dims); DQ_H5SYM(H5Dclose); DQ_H5SYM(H5Eset_auto2);
 #undef DQ_H5SYM
         if (api.H5open() < 0) throw std::runtime_error("results_h5: H5open failed");
+        api.H5Eset_auto2(0 /* H5E_DEFAULT */, nullptr, nullptr);      // failures are reported through exceptions, not HDF5's stderr stack dumps
         api.native_double = *reinterpret_cast<hid_t*>(sym("H5T_NATIVE_DOUBLE_g"));   // what the H5T_NATIVE_DOUBLE macro expands to
         return api;
     }
