@@ -58,7 +58,7 @@ def test_to_ldr(hip, orc, n):
     assert close(R, Ro, 1e-9) and close(np.abs(L), np.abs(Lo), 1e-9)
 
 
-@pytest.mark.parametrize("n", [16, 64, 256])
+@pytest.mark.parametrize("n", [16, 36, 64, 100, 128, 144, 256])
 def test_ldr_products_and_inverses(hip, orc, n):
     rng = np.random.default_rng(200 + n)
     M1 = graded(rng, n); M2 = graded(rng, n).T
