@@ -4,7 +4,7 @@ ARCH  ?= gfx950
 CXX   ?= g++
 HIPFLAGS ?= -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-function
 CSRC := dqmc_amd/csrc
-OBJS := $(CSRC)/gemm.o $(CSRC)/elementwise.o $(CSRC)/update.o $(CSRC)/qr.o $(CSRC)/qr_onchip.o $(CSRC)/qr_colown.o $(CSRC)/qr_coop.o $(CSRC)/lu.o $(CSRC)/lu_blocked.o $(CSRC)/lu_gj.o $(CSRC)/engine.o
+OBJS := $(CSRC)/gemm.o $(CSRC)/elementwise.o $(CSRC)/update.o $(CSRC)/qr.o $(CSRC)/qr_onchip.o $(CSRC)/qr_colown.o $(CSRC)/qr_coop.o $(CSRC)/lu.o $(CSRC)/lu_blocked.o $(CSRC)/lu_gj.o $(CSRC)/engine.o $(CSRC)/replica.o
 
 all: dqmc_amd/libdqmc_hip.so dqmc_amd/libdqmc_host.so dqmc_amd/dqmc_driver oracle
 
@@ -16,13 +16,13 @@ $(CSRC)/qr_colown_regs.inc: scripts/gen_qr_colown_regs.py
 	python3 scripts/gen_qr_colown_regs.py
 
 dqmc_amd/libdqmc_hip.so: $(OBJS)
-	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ $(OBJS)
+	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ $(OBJS) -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
 
-dqmc_amd/libdqmc_host.so: dqmc_amd/host/host_capi.cpp dqmc_amd/host/dqmc_host.hpp dqmc_amd/host/results_h5.hpp include/dqmc_hip.h
-	$(CXX) -O2 -std=c++17 -fPIC -shared -Iinclude -Idqmc_amd/host -o $@ dqmc_amd/host/host_capi.cpp -ldl
+dqmc_amd/libdqmc_host.so: dqmc_amd/host/host_capi.cpp dqmc_amd/host/dqmc_host.hpp dqmc_amd/host/results_h5.hpp include/dqmc_hip.h dqmc_amd/libdqmc_hip.so
+	$(CXX) -O2 -std=c++17 -fPIC -shared -pthread -Iinclude -Idqmc_amd/host -o $@ dqmc_amd/host/host_capi.cpp -Ldqmc_amd -ldqmc_hip -ldl -Wl,-rpath,'$$ORIGIN'
 
 dqmc_amd/dqmc_driver: dqmc_amd/host/main.cpp dqmc_amd/host/dqmc_host.hpp dqmc_amd/host/results_h5.hpp include/dqmc_hip.h dqmc_amd/libdqmc_hip.so
-	$(CXX) -O2 -std=c++17 -Iinclude -Idqmc_amd/host -o $@ dqmc_amd/host/main.cpp -Ldqmc_amd -ldqmc_hip -ldl -Wl,-rpath,'$$ORIGIN'
+	$(CXX) -O2 -std=c++17 -pthread -Iinclude -Idqmc_amd/host -o $@ dqmc_amd/host/main.cpp -Ldqmc_amd -ldqmc_hip -ldl -Wl,-rpath,'$$ORIGIN'
 
 oracle:
 	$(MAKE) -C oracle

@@ -11,9 +11,13 @@ config); --chains-per-gpu C batches C independent chains into every kernel
 launch.  Inputs are synthetic and resident in HBM before the timed region
 (only the per-sweep random stream, 2.6 MB/chain, is uploaded asynchronously).
 
-For N > 1 the driver launches one rank per GPU with torch.distributed.run;
-chains never communicate during sweeps (source/main.cpp:128-171), so there is
-no data-path collective: scaling is weak, value = total sweeps / max time.
+For N > 1 there is one rank per GPU (the reference's MPI ranks, source/main.cpp:20-37): either an
+outer launcher (torch.distributed.run) has set RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*, or -- plain
+`python bench.py --gpus N` -- this process spawns the N ranks itself before it touches the GPU and relays
+rank 0's JSON line.  Chains never communicate during sweeps (source/main.cpp:128-171), so there is no
+data-path collective: scaling is weak, value = total sweeps / max time.  After the timed region the ranks
+run two replica-exchange rounds over the library's RCCL transport (dqmc_replica_exchange_round; cfg 4's
+wire) and report them under "replica_exchange" -- outside `value`.
 """
 import argparse
 import json
@@ -51,6 +55,9 @@ def parity_vs_cpu(model, orc, lib, device, config):
         s1, s2 = model.random_stream(rng), model.random_stream(rng)
         for e in (g, c):
             e.sweep_0_to_beta(*s1); e.sweep_beta_to_0(*s2)
+        sg, sc_ = g.stats(), c.stats()
+        out["sweep_stats"] = {"gpu": {"acceptance": sg.n_accepted / max(1, sg.n_proposed), "max_wrap_err": sg.max_err, "mean_wrap_err": sg.mean_err},
+                              "cpu": {"acceptance": sc_.n_accepted / max(1, sc_.n_proposed), "max_wrap_err": sc_.max_err, "mean_wrap_err": sc_.mean_err}}
         Gg, Gc = g.get_G(), c.get_G()
         out["max_abs_dG_after_sweep"] = float(np.abs(Gg - Gc).max())
         out["max_abs_G_after_sweep"] = float(np.abs(Gc).max())
@@ -73,7 +80,9 @@ def cpu_baseline(model, seed, budget_s=20.0, lib=None, device=0, config="cfg3"):
     try:
         if lib is not None:
             parity = parity_vs_cpu(model, orc, lib, device, config)
-        e = model.engine(orc); e.set_fields(model.random_fields(seed)); e.init()
+        gold = os.path.join(ROOT, "tests", "golden", f"{config}_therm.npz")
+        start_fields = (lambda k: np.load(gold)["fields"]) if os.path.exists(gold) else (lambda k: model.random_fields(seed + k))   # same start as the GPU run
+        e = model.engine(orc); e.set_fields(start_fields(0)); e.init()
         rng = np.random.default_rng(seed)
         e.sweep_0_to_beta(*model.random_stream(rng)); e.sweep_beta_to_0(*model.random_stream(rng))   # warm-up sweep
         n = 0; t0 = time.perf_counter()
@@ -89,7 +98,7 @@ def cpu_baseline(model, seed, budget_s=20.0, lib=None, device=0, config="cfg3"):
         K = max(1, min(8, os.cpu_count() or 1))
         counts = [0] * K; times = [0.0] * K
         def chain(i):
-            ei = model.engine(orc); ei.set_fields(model.random_fields(seed + 1 + i)); ei.init()
+            ei = model.engine(orc); ei.set_fields(start_fields(1 + i)); ei.init()
             ri = np.random.default_rng(seed + 1 + i)
             ei.sweep_0_to_beta(*model.random_stream(ri)); ei.sweep_beta_to_0(*model.random_stream(ri))
             t_0 = time.perf_counter()
@@ -110,11 +119,74 @@ def cpu_baseline(model, seed, budget_s=20.0, lib=None, device=0, config="cfg3"):
     finally:
         orc.set_backend("builtin")
     out = {"value": n / dt, "unit": "sweeps/s", "cores": 1, "kind": "port",
-           "sample": f"{n} sweeps of 1 chain after 1 warm-up sweep, single thread, {backend}"}
+           "sample": f"{n} sweeps of 1 chain after 1 warm-up sweep, single thread, {backend}",
+           "nproc": os.cpu_count(), "flags": "g++ -O3 -march=native -fno-math-errno (no -ffast-math), oracle/Makefile"}
     if multi is not None:
         out["all_cores"] = multi
     if parity is not None:
         out["max_dG_vs_cpu"] = parity
+    return out
+
+
+def spawn_ranks(n: int, argv, extra_env=None, timeout=None) -> int:
+    """Start n fresh rank processes of this script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set) and wait for them;
+    their stdout / stderr pass through.  Returns the largest exit code.  Called before the parent makes any GPU call."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        env.update(extra_env or {})
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    rc = 0
+    try:
+        for p_ in procs:
+            rc = max(rc, abs(p_.wait(timeout=timeout)))
+    except BaseException:
+        for p_ in procs:
+            if p_.poll() is None:
+                p_.kill()                           # exactly the processes started here
+        raise
+    return rc
+
+
+def replica_exchange_check(lib, eng, d, rounds=2, timeout_s=120.0):
+    """Two rounds of dqmc_replica_exchange_round among the ranks over the RCCL transport (one rank per GPU), after the
+    timed region: the id travels over torch.distributed, the swaps HBM to HBM.  Guarded by a watchdog: a communicator that
+    never forms is reported, not waited for."""
+    import threading
+    import torch.distributed as dist
+    out = {"transport": "rccl", "rounds": rounds}
+    done = threading.Event()
+
+    def body():
+        try:
+            ids = [lib.comm_unique_id() if d.rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            comm = lib.comm_rccl(ids[0], d.world, d.rank, d.local_rank)
+            comm.barrier()
+            rng = np.random.default_rng(4000 + d.rank)
+            res = []
+            t0 = time.perf_counter()
+            for attempt in range(1, rounds + 1):
+                r = comm.exchange_round(eng, attempt, float(rng.random()))
+                res.append({"partner": r.partner, "decider": r.decider, "accepted": r.accepted, "deltaS": r.deltaS})
+            comm.barrier()
+            out["ms_per_round"] = 1e3 * (time.perf_counter() - t0) / rounds
+            out["rank0"] = res
+            acc = comm.allreduce_sum([float(sum(x["accepted"] for x in res))])
+            out["accepted_pair_ends"] = int(acc[0]); out["pair_ends"] = d.world * rounds
+            comm.close()
+        except Exception as e:                      # noqa: BLE001
+            out["error"] = repr(e)
+        done.set()
+    th = threading.Thread(target=body, daemon=True); th.start()
+    if not done.wait(timeout_s):
+        out["error"] = f"no completion within {timeout_s:.0f} s"
+        out["hung"] = True
     return out
 
 
@@ -135,12 +207,40 @@ def main():
     ap.add_argument("--rehearse-shared-gpu", action="store_true",
                     help="functional rehearsal of the N > 1 path on a box with fewer GPUs than ranks: gloo rendezvous, ranks share devices "
                          "(local_rank %% device_count); the timing is meaningless")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="rendezvous, barrier and max-over-ranks only (gloo, no engine, no GPU): the CPU test of the N > 1 launch path")
+    ap.add_argument("--no-replica-exchange", action="store_true", help="skip the RCCL replica-exchange rounds after the timed region (N > 1)")
     args = ap.parse_args()
+
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        # plain `python bench.py --gpus N`: this process becomes the launcher.  It makes no GPU call: the device count comes from
+        # torch.cuda.device_count(), which does not initialise the runtime on this image
+        if not (args.rehearse_shared_gpu or args.launch_check):
+            import torch
+            have = torch.cuda.device_count()
+            if have < args.gpus:
+                print(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) visible (use --rehearse-shared-gpu for a functional rehearsal)", file=sys.stderr)
+                sys.exit(2)
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+    if env_world is not None and int(env_world) != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} does not match WORLD_SIZE={env_world} set by the launcher", file=sys.stderr)
+        sys.exit(2)
 
     import torch
     from dqmc_amd.launch import barrier as dist_barrier, dist_init, finalize, max_over_ranks
-    d = dist_init("gloo" if args.rehearse_shared_gpu else None)      # WORLD_SIZE > 1: backend "nccl" (= RCCL) on GPUs
+    d = dist_init("gloo" if (args.rehearse_shared_gpu or args.launch_check) else None)      # WORLD_SIZE > 1: backend "nccl" (= RCCL) on GPUs
     rank, world, local_rank = d.rank, d.world, d.local_rank
+    if args.launch_check:
+        dist_barrier(d)
+        t = max_over_ranks(d, 1.0 + rank)
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": world, "max_over_ranks": t, "backend": d.backend}), flush=True)
+        finalize(d)
+        return
+    if not args.rehearse_shared_gpu and torch.cuda.device_count() < world:
+        print(f"bench.py: {world} ranks but only {torch.cuda.device_count()} GPU(s) visible", file=sys.stderr)
+        sys.exit(2)
 
     import dqmc_amd
     lib = dqmc_amd.lib()
@@ -149,7 +249,15 @@ def main():
     model = dqmc_amd.HubbardModel(**dqmc_amd.CONFIGS[args.config])
     C = args.chains_per_gpu
     eng = model.engine(lib, device=(local_rank % lib.device_count()) if args.rehearse_shared_gpu else local_rank, n_chains=C)
-    fields = np.stack([model.random_fields(12345 + rank * C + c) for c in range(C)])
+    # thermalise before timing.  When the config has a thermalised fixture (fields after CPU sweeps from the
+    # seeded i.i.d. start, tests/golden/make_golden.py) every chain starts from it and diverges at once through its own random
+    # stream; otherwise i.i.d. fields with seed 12345 + chain id, and --warmup should then be >= 20
+    gold = os.path.join(ROOT, "tests", "golden", f"{args.config}_therm.npz")
+    if os.path.exists(gold):
+        f0 = np.load(gold)["fields"]
+        fields = np.stack([f0 for _ in range(C)]); start = "thermalised fixture tests/golden/%s_therm.npz + %d warm-up sweeps" % (args.config, args.warmup)
+    else:
+        fields = np.stack([model.random_fields(12345 + rank * C + c) for c in range(C)]); start = "iid random fields (seed 12345 + chain) + %d warm-up sweeps" % args.warmup
     eng.set_fields(fields); eng.init()
     rng = np.random.default_rng(777 + rank)
 
@@ -196,6 +304,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.config}: {model.L1}x{model.L2} Hubbard U={model.U} beta={model.beta} Ltau={model.nt} n_stab={model.n_stab} t=1 mu=-0.1",
                        "chains_per_gpu": C, "n_chains_total": world * C, "parallelism": f"independent chains, {world} gpu x {C} chain"},
+            "start": start,
             "acceptance": acc_rate, "max_wrap_err": s1.max_err, "mean_wrap_err": s1.mean_err,
             "roofline": {"kernel": "local update of one time slice (slice_kernel: walk + flush roles)", "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -250,7 +359,17 @@ def main():
             for (ee, _, _) in engs: ee.close()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model, 12345, args.cpu_budget, lib, local_rank, args.config)
+        if args.rehearse_shared_gpu:
+            out["rehearsal"] = True                  # ranks share devices: the launch path is exercised, the number means nothing
+    rex = None
+    if world > 1 and C == 1 and not args.no_replica_exchange and not args.rehearse_shared_gpu:
+        rex = replica_exchange_check(lib, eng, d)
+    if rank == 0:
+        if rex is not None:
+            out["replica_exchange"] = rex
         print(json.dumps(out), flush=True)
+    if rex is not None and rex.get("hung"):
+        os._exit(0 if rank == 0 else 3)              # a communicator that never formed cannot be torn down either
     eng.close()
     finalize(d)
 

@@ -10,8 +10,8 @@ from __future__ import annotations
 import os
 from functools import lru_cache
 
-from .abi import ABI_SYMBOLS, DqmcError, DqmcLib, Engine, Stats  # noqa: F401
-from .model import HubbardModel, ghq_tables, CONFIGS  # noqa: F401
+from .abi import ABI_SYMBOLS, Comm, DqmcError, DqmcLib, Engine, ExchangeResult, Stats  # noqa: F401
+from .model import HubbardModel, ghq_tables, CONFIGS, CFG4_BETAS  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HIP_LIB_PATH = os.path.join(_HERE, "libdqmc_hip.so")

@@ -49,7 +49,20 @@ ABI_SYMBOLS = [
     "update_kernel_time", "set_profiling",
     "measure_equal_time", "measure_accumulate", "measure_fetch",
     "sweep_unequal_time", "get_G_tau", "measure_unequal_time", "measure_unequal_fetch",
+    "comm_unique_id", "comm_create_rccl", "comm_create_callbacks", "comm_destroy", "comm_rank", "comm_world_size",
+    "comm_transport", "comm_barrier", "comm_allreduce_sum", "partner_rank", "replica_exchange_round",
 ]
+
+UNIQUE_ID_BYTES = 128
+# dqmc_sendrecv_fn: int (*)(void* user, const void* send, void* recv, size_t bytes, int partner, int tag)
+SENDRECV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int)
+
+
+class ExchangeResult(C.Structure):
+    """dqmc_exchange_result of include/dqmc_hip.h."""
+    _fields_ = [("partner", C.c_int), ("decider", C.c_int), ("accepted", C.c_int), ("pad", C.c_int),
+                ("S", C.c_double), ("S_prime", C.c_double), ("S_partner", C.c_double), ("S_prime_partner", C.c_double),
+                ("deltaS", C.c_double)]
 
 
 def _f64(a) -> np.ndarray:
@@ -106,6 +119,17 @@ class DqmcLib:
             g("get_G_tau").argtypes = [C.c_void_p, C.c_int, C.c_int, c_double_p]
             g("measure_unequal_time").argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, c_double_p]
             g("measure_unequal_fetch").argtypes = [C.c_void_p, c_double_p, c_int64_p, C.c_int]
+        if self.has_symbol("replica_exchange_round"):
+            g("comm_unique_id").argtypes = [C.c_void_p]
+            g("comm_create_rccl").argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_int, C.c_int]
+            g("comm_create_callbacks").argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, SENDRECV_FN, C.c_void_p]
+            g("comm_destroy").argtypes = [C.c_void_p]; g("comm_destroy").restype = None
+            g("comm_rank").argtypes = [C.c_void_p]; g("comm_world_size").argtypes = [C.c_void_p]
+            g("comm_transport").argtypes = [C.c_void_p]; g("comm_transport").restype = C.c_char_p
+            g("comm_barrier").argtypes = [C.c_void_p]
+            g("comm_allreduce_sum").argtypes = [C.c_void_p, c_double_p, C.c_int]
+            g("partner_rank").argtypes = [C.c_int, C.c_int, C.c_int]
+            g("replica_exchange_round").argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.POINTER(ExchangeResult)]
         g("to_ldr").argtypes = [C.c_int] + [c_double_p] * 4
         g("ldr_mul_mat").argtypes = [C.c_int] + [c_double_p] * 7
         g("mat_mul_ldr").argtypes = [C.c_int] + [c_double_p] * 7
@@ -182,6 +206,79 @@ class DqmcLib:
 
     def engine(self, *args, **kw) -> "Engine":
         return Engine(self, *args, **kw)
+
+    # -- replica exchange: a dqmc_comm plays MPI_COMM_WORLD (source/update.cpp:47-117) --
+    def partner_rank(self, rank: int, world: int, attempt: int) -> int:
+        return int(self._sym("partner_rank")(rank, world, attempt))
+
+    def comm_unique_id(self) -> bytes:
+        buf = C.create_string_buffer(UNIQUE_ID_BYTES)
+        self.check(self._sym("comm_unique_id")(buf))
+        return buf.raw
+
+    def comm_rccl(self, uid: bytes, world: int, rank: int, device: int) -> "Comm":
+        h = C.c_void_p()
+        self.check(self._sym("comm_create_rccl")(C.byref(h), C.c_char_p(uid), world, rank, device))
+        return Comm(self, h)
+
+    def comm_callbacks(self, world: int, rank: int, fn) -> "Comm":
+        """fn(send: bytes, partner: int, tag: int) -> bytes: a blocking pairwise exchange (MPI_Sendrecv shape)."""
+        def tramp(_user, send, recv, nbytes, partner, tag):
+            try:
+                got = fn(C.string_at(send, nbytes), int(partner), int(tag))
+                if len(got) != nbytes:
+                    return -2
+                C.memmove(recv, got, nbytes)
+                return 0
+            except Exception:
+                return -1
+        cb = SENDRECV_FN(tramp)
+        h = C.c_void_p()
+        self.check(self._sym("comm_create_callbacks")(C.byref(h), world, rank, cb, None))
+        return Comm(self, h, keep=cb)
+
+
+class Comm:
+    """Handle onto a dqmc_comm."""
+
+    def __init__(self, lib: "DqmcLib", h, keep=None):
+        self.lib, self._h, self._keep = lib, h, keep
+
+    @property
+    def rank(self) -> int:
+        return int(self.lib._sym("comm_rank")(self._h))
+
+    @property
+    def world(self) -> int:
+        return int(self.lib._sym("comm_world_size")(self._h))
+
+    @property
+    def transport(self) -> str:
+        return self.lib._sym("comm_transport")(self._h).decode()
+
+    def barrier(self):
+        self.lib.check(self.lib._sym("comm_barrier")(self._h))
+
+    def allreduce_sum(self, x) -> np.ndarray:
+        v = np.ascontiguousarray(x, dtype=np.float64).copy()
+        self.lib.check(self.lib._sym("comm_allreduce_sum")(self._h, _p(v), int(v.size)))
+        return v
+
+    def exchange_round(self, engine: "Engine", attempt: int, u: float) -> ExchangeResult:
+        """dqmc_replica_exchange_round: `attempt` is the counter after the reference's exchange_attempt++."""
+        res = ExchangeResult()
+        self.lib.check(self.lib._sym("replica_exchange_round")(engine._h, self._h, int(attempt), float(u), C.byref(res)))
+        return res
+
+    def close(self):
+        if self._h is not None:
+            self.lib._sym("comm_destroy")(self._h); self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Engine:

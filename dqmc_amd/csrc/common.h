@@ -11,6 +11,8 @@
 #include <cstdint>
 #include <string>
 
+struct dqmc_engine;
+
 namespace dq {
 
 constexpr int WAVE = 64;
@@ -26,6 +28,12 @@ const char* get_error();
             ::dq::set_error(std::string(#call) + ": " + hipGetErrorString(_e));         \
             return -2; /* DQMC_ENODEVICE */                                             \
         }                                                                               \
+    } while (0)
+
+#define DQ_TRY_RC(expr)             \
+    do {                            \
+        int _rc = (expr);           \
+        if (_rc != 0) return _rc;   \
     } while (0)
 
 // A batched column-major matrix: chain c lives at p + c*stride (stride 0 =
@@ -157,7 +165,23 @@ struct UpdateDesc {
 constexpr int UPDATE_KD = 32;    // delayed-update window (accepted flips per flush)
 // one slice = reset + windows x (scan kernel, flush kernel)
 int launch_update_slice(const UpdateDesc& d, int l, int acc_slot, int n_chains, hipStream_t s);
+// CU reservation for the persistent single-launch slice kernel (see update.hip); an engine that holds one passes slice_sync
+bool slice_reserve(int device, int n, int n_chains);
+void slice_release(int device, int n, int n_chains);
 // standalone Sherman-Morrison rank-1 update (source/model.cpp:124-138), whole-chip streaming kernel
 int launch_rank1(Mat G, int i, double delta, double* scratch /*2n+1 doubles per chain*/, long scratch_stride, int n, int n_chains, hipStream_t s);
+
+// ---- per-device kernel attributes (dynamic LDS > 64 KiB), set once per device by init_device_kernels (engine.hip) ----
+int update_init_device();
+int qr_init_device();
+int qr_colown_init_device();
+int qr_onchip_init_device();
+int init_device_kernels(int device);
+
+// ---- engine.hip internals replica.hip needs: the HBM-resident HS fields of a single-chain engine ----
+struct EngineFieldsView { int device, n, nt, n_chains; int8_t* fields; hipStream_t stream; };
+int engine_fields_view(dqmc_engine* h, EngineFieldsView* v);
+// the device fields were overwritten in place: rebuild the exp(+-g eta) tables, the stack and G are stale until dqmc_init
+int engine_fields_changed(dqmc_engine* h);
 
 }  // namespace dq

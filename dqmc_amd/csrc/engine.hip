@@ -30,6 +30,18 @@ const char* get_error() { return g_err.c_str(); }
         if (_rc != 0) return _rc; \
     } while (0)
 
+// hipFuncSetAttribute is per device: every device an engine (or the stateless context) lives on gets the attributes once
+int init_device_kernels(int device) {
+    static std::mutex mu; static bool done[64] = {};
+    std::lock_guard<std::mutex> lk(mu);
+    if (device < 0 || device >= 64) { set_error("device ordinal out of range"); return -1; }
+    if (done[device]) return 0;
+    DQ_HIP(hipSetDevice(device));
+    DQ_TRY(update_init_device()); DQ_TRY(qr_init_device()); DQ_TRY(qr_colown_init_device()); DQ_TRY(qr_onchip_init_device());
+    done[device] = true;
+    return 0;
+}
+
 // ---------------------------------------------------------------------------
 // Workspace + stable linear algebra on device (stablelinalg.cpp restated as
 // launch sequences).  Shared by the engine and the stateless ABI calls.
@@ -66,6 +78,7 @@ struct Ctx {
     int init(int n_, int C_, int device_) {
         n = n_; C = C_; device = device_; nn = (long)n * n;
         DQ_HIP(hipSetDevice(device));
+        DQ_TRY(init_device_kernels(device));
         DQ_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         DQ_HIP(hipMalloc(&pool, sizeof(double) * NT * C * nn));
         DQ_HIP(hipMalloc(&vpool, sizeof(double) * 8 * C * n));
@@ -223,6 +236,7 @@ struct Engine {
     double* utMeasNow = nullptr; double* utMeasSum = nullptr; long long ut_meas_count = 0;     // [C][3][nt + 1][n] dynamical observables: last / bin sums
     long long meas_count = 0;                                    // measurements accumulated in meas_sum
     char* slice_sync = nullptr;                                  // [C][64 B] hand-off words of the persistent slice kernel
+    bool persistent = false;                                     // holds a CU reservation for the single-launch slice kernel (slice_reserve)
     int* acc = nullptr;                                          // [C][nt]
     double* err = nullptr;                                       // [C][n_stack]
     DevStats* dstats = nullptr;                                  // [C]
@@ -246,6 +260,7 @@ struct Engine {
 
     ~Engine() {
         if (s) (void)hipStreamSynchronize(s);
+        if (persistent) slice_release(device, n, C);
         for (auto& p : ev_pairs) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
         if (stage_free) (void)hipEventDestroy(stage_free);
         void* ptrs[] = {utMeasNow, utMeasSum, utG[0], utG[1], utG[2], utTmp, utErr, utL[0], utL[1], utD[0], utD[1], utR[0], utR[1], utP[0], utP[1], meas_now, meas_sum, GT, slice_sync, prep, stackP, expK, invexpK, fields, expv, invexpv, tabs, tab8, G, Gtmp, bb0, bb1, stackL, stackD, stackR, tmpL, tmpD, tmpR,
@@ -264,6 +279,7 @@ struct Engine {
         if (nt % n_stab != 0) loc_l_end[n_stack - 1] = nt % n_stab - 1;                    // source/dqmc.cpp:13-18
         g_host.assign(g, g + C); gamma_host.assign(gamma, gamma + 4); eta_host.assign(eta, eta + 4);
         DQ_TRY(ctx.init(n, C, device)); s = ctx.stream;
+        persistent = slice_reserve(device, n, C);
         DQ_TRY(dalloc(&expK, C * nn)); DQ_TRY(dalloc(&invexpK, C * nn));
         DQ_TRY(dalloc(&fields, (size_t)C * nt * n)); DQ_TRY(dalloc(&expv, (size_t)C * nt * n)); DQ_TRY(dalloc(&invexpv, (size_t)C * nt * n));
         DQ_TRY(dalloc(&tabs, C)); DQ_TRY(dalloc(&tab8, (size_t)C * 8));
@@ -348,7 +364,7 @@ struct Engine {
     UpdateDesc udesc() const {
         UpdateDesc d; d.G = mG(); d.fields = fields; d.f_stride = (long)nt * n; d.expv = expv; d.invexpv = invexpv; d.v_stride = (long)nt * n;
         d.tabs = tabs; d.perm = rs_perm; d.kprop = rs_k; d.u = rs_u; d.rs_stride = (long)nt * n; d.Upanel = Upanel; d.Wpanel = Wpanel;
-        d.panel_stride = (long)UPDATE_KD * n; d.state = state; d.state_stride = 4; d.prep = prep; d.prep_stride = 4L * n; d.slice_sync = slice_sync; d.GT = Mat{GT, nn}; d.gt_valid = gt_valid ? 1 : 0; d.info = ctx.info(); d.acc_out = acc; d.acc_stride = nt; d.n = n; d.nt = nt;
+        d.panel_stride = (long)UPDATE_KD * n; d.state = state; d.state_stride = 4; d.prep = prep; d.prep_stride = 4L * n; d.slice_sync = persistent ? slice_sync : nullptr; d.GT = Mat{GT, nn}; d.gt_valid = gt_valid ? 1 : 0; d.info = ctx.info(); d.acc_out = acc; d.acc_stride = nt; d.n = n; d.nt = nt;
         return d;
     }
     int local_update(int l) {
@@ -534,6 +550,21 @@ static LdrRef slot(Ctx* c, double* extra, int k) {     // k = 0,1,2: LDR-sized s
 using namespace dq;
 
 struct dqmc_engine { Engine e; };
+
+namespace dq {
+int engine_fields_view(dqmc_engine* h, EngineFieldsView* v) {
+    if (!h || !v) { set_error("null engine"); return DQMC_EINVAL; }
+    Engine& e = h->e;
+    v->device = e.device; v->n = e.n; v->nt = e.nt; v->n_chains = e.C; v->fields = e.fields; v->stream = e.s;
+    return 0;
+}
+int engine_fields_changed(dqmc_engine* h) {
+    if (!h) { set_error("null engine"); return DQMC_EINVAL; }
+    Engine& e = h->e;
+    e.stack_valid = false; e.gt_valid = false;
+    return launch_build_expv(e.fields, (long)e.nt * e.n, e.nt, e.n, e.tab8, e.expv, e.invexpv, (long)e.nt * e.n, e.C, e.s);
+}
+}  // namespace dq
 
 #define API_LOCK std::lock_guard<std::mutex> _lk(g_ctx_mu)
 #define CHECK_E(e) if (!(e)) { set_error("null engine"); return DQMC_EINVAL; }

@@ -371,16 +371,20 @@ static int launch_to_ldr_nr(Mat A, Mat L, Vec d, Mat R, QrWork w, int n, int n_c
         return 0;
     }
     const size_t lds = sizeof(double) * ((size_t)3 * n + (size_t)16 * n + 32) + sizeof(int) * (16 + (size_t)n) + 64;
-    static bool attr_set = false;
-    if (!attr_set) {
-        DQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(qrcp_kernel<NR>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
     hipLaunchKernelGGL((qrcp_kernel<NR>), dim3(1, n_chains), dim3(1024), lds, s, A, w, n);
     hipLaunchKernelGGL((formq_kernel<4 * NR>), dim3((n + 15) / 16, n_chains), dim3(256), 0, s, CMat(A), (const double*)w.tau, w.tau_stride,
                        (const int*)w.jpvt, w.jpvt_stride, L, n);
     hipLaunchKernelGGL(assemble_r_kernel, dim3(n, n_chains), dim3(128), 0, s, CMat(A), (const int*)w.jpvt, w.jpvt_stride, d, R, n);
     DQ_HIP(hipGetLastError());
+    return 0;
+}
+
+int qr_init_device() {
+    DQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(qrcp_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    DQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(qrcp_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    DQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(qrcp_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    DQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(qrcp_kernel<9>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    DQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(qrcp_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     return 0;
 }
 

@@ -386,13 +386,13 @@ __global__ __launch_bounds__(CO_T) __attribute__((amdgpu_num_vgpr(32))) void qrc
 }
 #undef CO_X
 
+int qr_colown_init_device() {
+    DQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(qrcp_colown_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    return 0;
+}
+
 int launch_qrcp_colown(Mat A, QrWork w, int n, int n_chains, hipStream_t s) {
     const size_t lds = sizeof(double) * (64 * CO_N + CO_N + 2 * CO_N + CO_N + 2 * CO_N + CO_N + CO_N + 8 + 4) + sizeof(int) * 2 * CO_N + 16 + 2 * CO_N + 64;
-    static bool attr_set = false;
-    if (!attr_set) {
-        DQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(qrcp_colown_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
     hipLaunchKernelGGL(qrcp_colown_kernel, dim3(1, n_chains), dim3(CO_T), lds, s, A, w, n);
     DQ_HIP(hipGetLastError());
     return 0;

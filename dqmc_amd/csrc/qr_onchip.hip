@@ -351,14 +351,14 @@ __global__ __launch_bounds__(OC_T) void qrcp_onchip_kernel(Mat Am, QrWork w, int
 #undef LCOL
 #undef COLOF
 
+int qr_onchip_init_device() {
+    DQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(qrcp_onchip_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    return 0;
+}
+
 int launch_qrcp_onchip(Mat A, QrWork w, int n, int n_chains, hipStream_t s) {
     if (n > OC_N) { set_error("on-chip QRCP supports n <= 256"); return -1; }
     const size_t lds = sizeof(double) * (2 * 16 * OC_T + 5 * OC_N + 8 + 8) + sizeof(int) * OC_N + 64;
-    static bool attr_set = false;
-    if (!attr_set) {
-        DQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(qrcp_onchip_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
     hipLaunchKernelGGL(qrcp_onchip_kernel, dim3(1, n_chains), dim3(OC_T), lds, s, A, w, n);
     DQ_HIP(hipGetLastError());
     return 0;

@@ -20,6 +20,7 @@
 //   flush_kernel<false>
 #include "common.h"
 #include <cstdlib>
+#include <mutex>
 #include "wave.h"
 
 namespace dq {
@@ -784,6 +785,47 @@ static int pick_kd(int n) {
     return (int)kd;
 }
 
+// ---- co-residency of the persistent slice kernel ------------------------------------------------------------------------
+// slice_kernel's 1 + (n/32)^2 workgroups per chain wait for each other, so all of them must be resident at once, and each
+// occupies a whole CU (512 VGPRs per lane: one wave per SIMD).  Engines therefore RESERVE their workgroups against the
+// device's CU count when they are created (hipDeviceProp_t::multiProcessorCount minus a margin for whatever else runs);
+// an engine that does not get its reservation -- many chains per engine, many engines per device -- takes the
+// scan / flush kernel pairs, which need nobody to be co-resident.  Kernels that do not spin (GEMMs, factorisations) finish
+// on their own and only delay a hand-off.  The reservation is per process: several PROCESSES sharing one GPU with
+// persistent engines should set DQMC_SLICE_MULTIKERNEL=1 (a hand-off that times out is reported, never a hang).
+static std::mutex g_resv_mu;
+static int g_resv_used[64] = {};
+static int g_resv_cap[64] = {};
+int slice_workgroups(int n, int n_chains) { const int tiles = (n + 31) / 32; return (1 + tiles * tiles) * n_chains; }
+bool slice_reserve(int device, int n, int n_chains) {
+    if (device < 0 || device >= 64 || n > 256) return false;
+    std::lock_guard<std::mutex> lk(g_resv_mu);
+    if (g_resv_cap[device] == 0) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) != hipSuccess) return false;
+        const char* m = getenv("DQMC_SLICE_CU_MARGIN");
+        g_resv_cap[device] = prop.multiProcessorCount - (m ? atoi(m) : 32);
+    }
+    const int want = slice_workgroups(n, n_chains);
+    if (g_resv_used[device] + want > g_resv_cap[device]) return false;
+    g_resv_used[device] += want;
+    return true;
+}
+void slice_release(int device, int n, int n_chains) {
+    if (device < 0 || device >= 64) return;
+    std::lock_guard<std::mutex> lk(g_resv_mu);
+    g_resv_used[device] -= slice_workgroups(n, n_chains);
+}
+
+// kernels with more than 64 KiB of dynamic LDS need the attribute on every device they run on (init_device_kernels, engine.hip)
+int update_init_device() {
+    DQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(scan_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    DQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(scan_kernel<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    DQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(slice_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    DQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(slice_solo_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    return 0;
+}
+
 int launch_update_slice(const UpdateDesc& d, int l, int acc_slot, int n_chains, hipStream_t s) {
     const int n = d.n;
     if (n > 1024) { set_error("local update kernel supports n_sites <= 1024"); return -1; }
@@ -791,13 +833,6 @@ int launch_update_slice(const UpdateDesc& d, int l, int acc_slot, int n_chains, 
     const int threads = ((n + 63) / 64) * 64;
     const bool regs = threads <= 256;                               // walk v3 (register-resident pending pairs, needs GT)
     const size_t lds = scan_lds_bytes(n, kd, regs);
-    static bool attr_set = false;
-    if (!attr_set) {
-        DQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(scan_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        DQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(scan_kernel<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        DQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(slice_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
     const int tiles = (n + 31) / 32;
     if (regs) {
         if (!d.GT.p) { set_error("local update: transposed workspace missing"); return -1; }
@@ -805,7 +840,7 @@ int launch_update_slice(const UpdateDesc& d, int l, int acc_slot, int n_chains, 
     }
     static const bool multi_kernel = getenv("DQMC_SLICE_MULTIKERNEL") != nullptr;      // A/B switch
     // persistent single-launch path: needs every workgroup of a chain resident at once, one per CU (the walk's LDS)
-    if (!multi_kernel && regs && d.slice_sync && (long)(1 + tiles * tiles) * n_chains <= 224) {
+    if (!multi_kernel && regs && d.slice_sync) {                    // slice_sync is only handed out with a CU reservation (slice_reserve)
         hipLaunchKernelGGL(slice_kernel, dim3(1 + tiles * tiles, n_chains), dim3(256), lds, s, d, reinterpret_cast<SliceSync*>(d.slice_sync), l, acc_slot, kd,
                            tiles, d.info);
         DQ_HIP(hipGetLastError());
@@ -816,8 +851,6 @@ int launch_update_slice(const UpdateDesc& d, int l, int acc_slot, int n_chains, 
     // flushes slower than the whole chip does, so the solo kernel pays once there are enough chains to occupy every CU
     static const bool solo_forced = getenv("DQMC_SLICE_SOLO") != nullptr;
     if (regs && !pairs && !multi_kernel && (n_chains >= 224 || solo_forced)) {
-        static bool solo_attr = false;
-        if (!solo_attr) { DQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(slice_solo_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); solo_attr = true; }
         hipLaunchKernelGGL(slice_solo_kernel, dim3(1, n_chains), dim3(256), lds, s, d, l, acc_slot, kd, 0);
         DQ_HIP(hipGetLastError());
         return 0;
@@ -837,8 +870,6 @@ int launch_update_slice(const UpdateDesc& d, int l, int acc_slot, int n_chains, 
         }
     }
     if (tail_solo) {
-        static bool solo_attr2 = false;
-        if (!solo_attr2) { DQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(slice_solo_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); solo_attr2 = true; }
         hipLaunchKernelGGL(slice_solo_kernel, dim3(1, n_chains), dim3(256), lds, s, d, l, acc_slot, kd, 1);
     }
     DQ_HIP(hipGetLastError());

@@ -26,15 +26,18 @@
 #include <array>
 #include <cmath>
 #include <cstdint>
+#include <condition_variable>
 #include <cstring>
+#include <deque>
 #include <fstream>
-#include <functional>
 #include <map>
+#include <mutex>
 #include <random>
 #include <sstream>
 #include <stdexcept>
 #include <string>
 #include <sys/stat.h>
+#include <tuple>
 #include <vector>
 
 #include "dqmc_hip.h"
@@ -388,6 +391,8 @@ public:
         dqmc_detail::check(dqmc_init(e_));
         LDRStack s; s.e_ = e_; s.n_stack_ = (size_t)n_stack_; s.n_ = model_.ns(); return s;
     }
+    // a handle onto the engine's current stack without rebuilding it
+    LDRStack stack_handle() { LDRStack s; s.e_ = e_; s.n_stack_ = (size_t)n_stack_; s.n_ = model_.ns(); return s; }
     // source/dqmc.cpp:61-72
     GF init_greenfunctions(LDRStack&) { GF g; download(g); return g; }
     void download(GF& g) {
@@ -445,40 +450,73 @@ public:
 };
 
 namespace update {
-// source/update.cpp:47-117.  The MPI_Sendrecv / MPI_Send / MPI_Recv calls of the reference are
-// supplied by the caller as three std::functions so the same code runs over RCCL (one rank per
-// GPU, dqmc_amd/replica.py does the transport with torch.distributed's "nccl" = RCCL backend),
-// over MPI, or in-process for tests.
-struct Transport {
-    std::function<void(const int64_t* send, int64_t* recv, size_t count, int partner)> sendrecv_fields;   // tag 0
-    std::function<double(double mine, int partner, int tag)> sendrecv_double;                              // tags 1, 2
-    std::function<bool(bool value, int partner, bool i_decide)> share_decision;                            // tag 3
-};
-inline void replica_exchange(int rank, int world_size, utility::random& rng, int& exchange_attempt, int& exchange_accepted,
-                             AttractiveHubbard& model, DQMC& sim, std::vector<GF>& greens, std::vector<LDRStack>& stacks, const Transport& tr) {
-    exchange_attempt++;
-    const int partner = partner_rank(rank, world_size, exchange_attempt);
-    if (partner < 0 || partner >= world_size) return;
-    sim.download_fields();
-    const std::vector<int64_t> my_fields = model.fields().fields();
-    std::vector<int64_t> partner_fields(my_fields.size());
-    tr.sendrecv_fields(my_fields.data(), partner_fields.data(), my_fields.size(), partner);
-    const double SC = sim.global_action();                                   // S_r({s}_r)
-    model.fields().set_fields(partner_fields);
-    for (int flv = 0; flv < model.n_flavor(); ++flv) { stacks[flv] = sim.init_stacks(flv); greens[flv] = sim.init_greenfunctions(stacks[flv]); }
-    const double SC_prime = sim.global_action();                             // S_r({s}_partner)
-    const double SC_prime_partner = tr.sendrecv_double(SC_prime, partner, 1);
-    const double SC_partner = tr.sendrecv_double(SC, partner, 2);
-    bool accept = false;
-    if (rank < partner) {
-        const double deltaS = (SC_prime + SC_prime_partner) - (SC + SC_partner);
-        accept = rng.bernoulli(std::min(1.0, std::exp(-deltaS)));
-        if (rank == 0) exchange_accepted += accept;
-        accept = tr.share_decision(accept, partner, true);
-    } else accept = tr.share_decision(false, partner, false);
-    if (!accept) {
-        model.fields().set_fields(my_fields);
-        for (int flv = 0; flv < model.n_flavor(); ++flv) { stacks[flv] = sim.init_stacks(flv); greens[flv] = sim.init_greenfunctions(stacks[flv]); }
-    }
+// The canonical uniform that rng.bernoulli(p) compares with p (include/utility.h:34-37): std::bernoulli_distribution on
+// std::mt19937 draws std::generate_canonical<double, 53>, i.e. exactly two words whatever p is, so the decision
+// "bernoulli(p)" can be taken wherever p becomes known as "u < p" (checked against the real thing in tests/test_host.py).
+inline double draw_bernoulli_uniform(utility::random& rng) {
+    std::mt19937& gen = rng.get_generator();
+    const std::mt19937::result_type w0 = gen(), w1 = gen();
+    double c = (static_cast<double>(w0) + static_cast<double>(w1) * 4294967296.0) / 18446744073709551616.0;
+    if (c >= 1.0) c = std::nextafter(1.0, 0.0);
+    return c;
 }
+
+// source/update.cpp:47-117.  `comm` plays MPI_COMM_WORLD (one rank per GPU): the field swap, the trial
+// re-initialisation, the two action exchanges, the decision by the lower rank and the restoring re-initialisation run
+// inside dqmc_replica_exchange_round on HBM-resident state (RCCL: device to device over xGMI); the host side keeps
+// what the reference keeps on the host -- the attempt counter, the partner rule, the decider's bernoulli draw from the
+// rank's utility::random, rank 0's acceptance counter -- and refreshes model.fields() and the GF / LDRStack handles.
+inline dqmc_exchange_result replica_exchange(int rank, int world_size, utility::random& rng, int& exchange_attempt, int& exchange_accepted,
+                                             AttractiveHubbard& model, DQMC& sim, std::vector<GF>& greens, std::vector<LDRStack>& stacks,
+                                             dqmc_comm* comm) {
+    exchange_attempt++;
+    dqmc_exchange_result res{}; res.partner = -1;
+    const int partner = partner_rank(rank, world_size, exchange_attempt);
+    if (partner < 0 || partner >= world_size) return res;                    // partner out of bounds: do nothing (:55-57)
+    if (dqmc_comm_rank(comm) != rank || dqmc_comm_world_size(comm) != world_size) throw std::invalid_argument("replica_exchange: communicator does not match rank / world_size");
+    const double u = rank < partner ? draw_bernoulli_uniform(rng) : 0.0;      // only the decider's generator advances (:96)
+    dqmc_detail::check(dqmc_replica_exchange_round(sim.handle(), comm, exchange_attempt, u, &res));
+    if (rank == 0) exchange_accepted += res.accepted;                        // :99-101
+    sim.download_fields();                                                   // model.fields(): partner's on acceptance, restored otherwise
+    for (int flv = 0; flv < model.n_flavor(); ++flv) { stacks[flv] = sim.stack_handle(); greens[flv] = sim.init_greenfunctions(stacks[flv]); }
+    return res;
+}
+
+// In-process stand-in for MPI_COMM_WORLD: `world` replicas run as threads of one process (one engine each, on one or
+// several GPUs) and meet in a mailbox.  endpoint(rank) + InProcessHub::sendrecv are the (user, fn) pair of
+// dqmc_comm_create_callbacks.  Used by the driver's single-process parallel-tempering mode and by the tests.
+class InProcessHub {
+    struct Key { int src, dst, tag; bool operator<(const Key& o) const { return std::tie(src, dst, tag) < std::tie(o.src, o.dst, o.tag); } };
+    std::mutex mu_; std::condition_variable cv_;
+    std::map<Key, std::deque<std::vector<char>>> box_;
+    int world_; bool aborted_ = false;
+public:
+    struct Endpoint { InProcessHub* hub; int rank; };
+private:
+    std::vector<Endpoint> eps_;
+public:
+    explicit InProcessHub(int world) : world_(world) { for (int r = 0; r < world; ++r) eps_.push_back({this, r}); }
+    int world() const { return world_; }
+    void abort() { std::lock_guard<std::mutex> lk(mu_); aborted_ = true; cv_.notify_all(); }
+    void* endpoint(int rank) { return &eps_.at(rank); }
+    static int sendrecv(void* user, const void* send, void* recv, size_t bytes, int partner, int tag) {
+        Endpoint* ep = static_cast<Endpoint*>(user); InProcessHub& h = *ep->hub;
+        if (partner < 0 || partner >= h.world_ || partner == ep->rank) return -1;
+        std::unique_lock<std::mutex> lk(h.mu_);
+        const char* p = static_cast<const char*>(send);
+        h.box_[Key{ep->rank, partner, tag}].emplace_back(p, p + bytes);
+        h.cv_.notify_all();
+        auto& q = h.box_[Key{partner, ep->rank, tag}];
+        h.cv_.wait(lk, [&] { return !q.empty() || h.aborted_; });
+        if (q.empty()) return -3;                                          // a replica failed: everybody leaves
+        if (q.front().size() != bytes) return -2;
+        std::memcpy(recv, q.front().data(), bytes); q.pop_front();
+        return 0;
+    }
+    dqmc_comm* make_comm(int rank) {
+        dqmc_comm* c = nullptr;
+        dqmc_detail::check(dqmc_comm_create_callbacks(&c, world_, rank, &InProcessHub::sendrecv, endpoint(rank)));
+        return c;
+    }
+};
 }  // namespace update

@@ -4,6 +4,10 @@
 #include "dqmc_host.hpp"
 #include "results_h5.hpp"
 
+#include <cstdio>
+#include <memory>
+#include <thread>
+
 extern "C" {
 
 int dqmc_host_abi_version(void) { return 1; }
@@ -128,6 +132,130 @@ long long dqmc_host_results_read(const char* file, const char* dataset, int* ndi
         if (err && errlen > 0) { std::strncpy(err, e.what(), errlen - 1); err[errlen - 1] = 0; }
         return -1;
     }
+}
+
+}  // extern "C"
+
+// ---- parallel tempering with in-process replicas (threads) -------------------------------------------------------
+// What source/main.cpp builds per MPI rank (rng, model at the rank's beta, DQMC, stacks, greens) for `world` replicas
+// of ONE process, their engines on the given devices, meeting in an update::InProcessHub.  The test-suite drives
+// update::replica_exchange through this on HIP engines (tests/test_gpu_parity.py) and checks it against CPU-oracle
+// engines fed with the same random streams; the driver's single-process PT mode is the same construction.
+namespace {
+struct PtReplica {
+    utility::random rng; AttractiveHubbard model; DQMC sim;
+    std::vector<LDRStack> stacks; std::vector<GF> greens; dqmc_comm* comm = nullptr;
+    int attempt = 0, accepted = 0;
+    PtReplica(const utility::parameters& p, const Lattice& lat, unsigned seed, double beta, int device)
+        : rng(seed), model(p, lat, rng, beta), sim(p, model, device), stacks(1), greens(1) {
+        stacks[0] = sim.init_stacks(0); greens[0] = sim.init_greenfunctions(stacks[0]);
+    }
+    ~PtReplica() { dqmc_comm_destroy(comm); }
+};
+struct PtWorld {
+    utility::parameters params; std::unique_ptr<Lattice> lat; std::unique_ptr<update::InProcessHub> hub;
+    std::vector<std::unique_ptr<PtReplica>> reps;
+    template <class F> int each(F&& f, char* err, int errlen) {
+        std::vector<std::thread> th; std::vector<std::string> errs(reps.size());
+        for (size_t r = 0; r < reps.size(); ++r) th.emplace_back([&, r] { try { f((int)r, *reps[r]); } catch (const std::exception& e) { errs[r] = e.what(); if (errs[r].empty()) errs[r] = "error"; hub->abort(); } });
+        for (auto& t : th) t.join();
+        for (size_t r = 0; r < reps.size(); ++r) if (!errs[r].empty()) {
+            if (err && errlen > 0) { std::snprintf(err, (size_t)errlen, "replica %zu: %s", r, errs[r].c_str()); }
+            return -1;
+        }
+        return 0;
+    }
+};
+}  // namespace
+
+extern "C" {
+
+void* dqmc_host_pt_create(const char* ini, int world, const double* betas, const unsigned int* seeds, const int* devices, char* err, int errlen) {
+    try {
+        std::unique_ptr<PtWorld> w(new PtWorld);
+        w->params = utility::parameters::from_string(ini);
+        w->lat.reset(new Lattice(w->params, {1.0, 0.0}, {0.0, 1.0}, {{0.0, 0.0}}));
+        w->hub.reset(new update::InProcessHub(world));
+        for (int r = 0; r < world; ++r) {
+            w->reps.emplace_back(new PtReplica(w->params, *w->lat, seeds[r], betas[r], devices ? devices[r] : 0));
+            w->reps.back()->comm = w->hub->make_comm(r);
+        }
+        return w.release();
+    } catch (const std::exception& e) {
+        if (err && errlen > 0) { std::strncpy(err, e.what(), errlen - 1); err[errlen - 1] = 0; }
+        return nullptr;
+    }
+}
+void dqmc_host_pt_destroy(void* p) { delete static_cast<PtWorld*>(p); }
+
+// model.fields().set_fields + init_stacks + init_greenfunctions of one replica
+int dqmc_host_pt_set_fields(void* p, int rank, const int64_t* fields, char* err, int errlen) {
+    try {
+        PtReplica& r = *static_cast<PtWorld*>(p)->reps.at(rank);
+        std::vector<int64_t> f(fields, fields + (size_t)r.model.nt() * r.model.ns());
+        r.model.fields().set_fields(f);
+        r.stacks[0] = r.sim.init_stacks(0); r.greens[0] = r.sim.init_greenfunctions(r.stacks[0]);
+        return 0;
+    } catch (const std::exception& e) { if (err && errlen > 0) { std::strncpy(err, e.what(), errlen - 1); err[errlen - 1] = 0; } return -1; }
+}
+// n_sweeps x (sweep_0_to_beta + sweep_beta_to_0) on every replica (concurrently = 1: the replicas' threads run at once, as ranks do)
+int dqmc_host_pt_sweeps(void* p, int n_sweeps, int concurrently, char* err, int errlen) {
+    PtWorld& w = *static_cast<PtWorld*>(p);
+    auto body = [&](int, PtReplica& r) {
+        for (int i = 0; i < n_sweeps; ++i) { r.sim.sweep_0_to_beta(r.greens, r.stacks); r.sim.sweep_beta_to_0(r.greens, r.stacks); }
+        r.sim.download(r.greens[0]);
+    };
+    if (concurrently) return w.each(body, err, errlen);
+    try { for (size_t r = 0; r < w.reps.size(); ++r) body((int)r, *w.reps[r]); return 0; }
+    catch (const std::exception& e) { if (err && errlen > 0) { std::strncpy(err, e.what(), errlen - 1); err[errlen - 1] = 0; } return -1; }
+}
+// one round of update::replica_exchange on every replica (source/main.cpp:146-153: barrier, then the exchange); results [world]
+int dqmc_host_pt_exchange(void* p, dqmc_exchange_result* results, char* err, int errlen) {
+    PtWorld& w = *static_cast<PtWorld*>(p);
+    const int world = (int)w.reps.size();
+    return w.each([&](int rank, PtReplica& r) {
+        dqmc_detail::check(dqmc_comm_barrier(r.comm));
+        results[rank] = update::replica_exchange(rank, world, r.rng, r.attempt, r.accepted, r.model, r.sim, r.greens, r.stacks, r.comm);
+    }, err, errlen);
+}
+// state of one replica: model.fields() (nt x nv column-major int64), greens[0].Gtt[0], log_det_M, S = global_action, counters
+int dqmc_host_pt_get(void* p, int rank, int64_t* fields, double* G, double* logdet, double* action, int* attempt, int* accepted, char* err, int errlen) {
+    try {
+        PtReplica& r = *static_cast<PtWorld*>(p)->reps.at(rank);
+        r.sim.download_fields(); r.sim.download(r.greens[0]);
+        if (fields) std::copy(r.model.fields().fields().begin(), r.model.fields().fields().end(), fields);
+        if (G) std::copy(r.greens[0].Gtt0.begin(), r.greens[0].Gtt0.end(), G);
+        if (logdet) *logdet = r.greens[0].log_det_M;
+        if (action) *action = r.sim.global_action();
+        if (attempt) *attempt = r.attempt;
+        if (accepted) *accepted = r.accepted;
+        return 0;
+    } catch (const std::exception& e) { if (err && errlen > 0) { std::strncpy(err, e.what(), errlen - 1); err[errlen - 1] = 0; } return -1; }
+}
+// the raw generator of a replica: lets a test advance a twin utility::random in lock-step
+unsigned int dqmc_host_pt_rng_peek(void* p, int rank) { std::mt19937 g = static_cast<PtWorld*>(p)->reps.at(rank)->rng.get_generator(); return g(); }
+
+// the canonical uniform bernoulli(p) compares with p (update::draw_bernoulli_uniform), for twins of a rank's generator
+double dqmc_host_rng_bernoulli_uniform(void* r) { return update::draw_bernoulli_uniform(*static_cast<utility::random*>(r)); }
+int dqmc_host_rng_bernoulli(void* r, double p) { return static_cast<utility::random*>(r)->bernoulli(p) ? 1 : 0; }
+
+// the in-process hub alone (no engine): `world` threads each exchange a few messages; returns 0 when every byte arrived
+int dqmc_host_hub_selftest(int world, int rounds) {
+    update::InProcessHub hub(world);
+    std::vector<int> bad(world, 0); std::vector<std::thread> th;
+    for (int r = 0; r < world; ++r) th.emplace_back([&, r] {
+        for (int a = 1; a <= rounds; ++a) {
+            const int partner = update::partner_rank(r, world, a);
+            std::vector<int64_t> s(1000 + a, (int64_t)r * 1000 + a), g(1000 + a, -1);
+            if (update::InProcessHub::sendrecv(hub.endpoint(r), s.data(), g.data(), s.size() * sizeof(int64_t), partner, 0) != 0) { bad[r]++; continue; }
+            for (int64_t v : g) if (v != (int64_t)partner * 1000 + a) { bad[r]++; break; }
+            double x = r + 0.5, y = -1; 
+            if (update::InProcessHub::sendrecv(hub.endpoint(r), &x, &y, sizeof(double), partner, 1) != 0 || y != partner + 0.5) bad[r]++;
+        }
+    });
+    for (auto& t : th) t.join();
+    int total = 0; for (int b : bad) total += b;
+    return total;
 }
 
 }  // extern "C"

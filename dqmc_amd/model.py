@@ -98,5 +98,10 @@ CONFIGS: Dict[str, dict] = {
     "cfg1": dict(L1=4, L2=4, U=4.0, beta=2.0, nt=20, n_stab=10),
     "cfg2": dict(L1=8, L2=8, U=4.0, beta=4.0, nt=80, n_stab=10),
     "cfg3": dict(L1=16, L2=16, U=8.0, beta=8.0, nt=200, n_stab=10),
+    # cfg 4 = replica exchange: one engine per inverse temperature (CFG4_BETAS), swaps over RCCL; `beta` here is rank 0's
+    "cfg4": dict(L1=16, L2=16, U=8.0, beta=8.0, nt=200, n_stab=10),
     "cfg5": dict(L1=24, L2=24, U=4.0, beta=10.0, nt=400, n_stab=10),
 }
+# BASELINE.json configs[3]: "16x16 2D Hubbard replica exchange across 8 inverse temperatures" (the list is not given there;
+# a geometric-ish ladder below the headline beta = 8, the shape of examples/parameters.in's [ParallelTempering] betas)
+CFG4_BETAS = [8.0, 7.0, 6.0, 5.0, 4.0, 3.5, 3.0, 2.5]

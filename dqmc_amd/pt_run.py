@@ -1,12 +1,14 @@
 #!/usr/bin/env python3
-"""Parallel-tempering driver (BASELINE.json configs[3]): one inverse temperature per rank / GPU,
-replica exchange every `sweep_steps` sweeps over RCCL (source/main.cpp:39-67,146-153).
+"""Parallel-tempering run (BASELINE.json configs[3]): one inverse temperature per rank / GPU, replica exchange every
+`sweep_steps` sweeps (source/main.cpp:39-67,146-153) through the library's own transport -- dqmc_replica_exchange_round
+over an RCCL communicator (include/dqmc_hip.h), the field arrays going HBM to HBM over xGMI.
 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \\
-        dqmc_amd/pt_run.py --betas 8,7,6,5,4,3.5,3,2.5 --sweeps 40 --sweep-steps 5
+        dqmc_amd/pt_run.py --sweeps 40 --sweep-steps 5
 
-The number of betas must equal the world size and the world size must be even, exactly the checks
-the reference makes before MPI_Abort (source/main.cpp:52-63)."""
+torch.distributed only carries the rendezvous (the 128-byte RCCL id) here.  The number of betas must equal the world
+size and the world size must be even, the checks the reference makes before MPI_Abort (source/main.cpp:52-63).  The C++
+driver (dqmc_amd/host/main.cpp) is the same loop without Python."""
 from __future__ import annotations
 
 import argparse
@@ -19,52 +21,62 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def run_pt(d, engine_factory, betas, L, U, nt, n_stab, therm, sweeps, sweep_steps, seed=1234, log=print):
-    """`engine_factory(model) -> Engine`; returns (sweeps/s of this rank, exchange_attempt, exchange_accepted)."""
+def run_pt(d, lib, betas, L, U, nt, n_stab, therm, sweeps, sweep_steps, seed=1234, log=print):
+    """Returns (sweeps/s of this rank, exchange_attempt, exchange_accepted of rank 0's pairs)."""
+    import torch.distributed as dist
     from dqmc_amd import HubbardModel
-    from dqmc_amd.launch import barrier, max_over_ranks, sum_over_ranks
-    from dqmc_amd.replica import replica_exchange
     if len(betas) != d.world:
         raise SystemExit(f"ERROR: The number of betas ({len(betas)}) must match the number of processes ({d.world}).")
     if d.world % 2 != 0:
         raise SystemExit(f"ERROR: currently number of processor ( nprocs = {d.world}) need to be even for replica exchange")
+    ids = [lib.comm_unique_id() if d.rank == 0 else None]
+    dist.broadcast_object_list(ids, src=0)
+    comm = lib.comm_rccl(ids[0], d.world, d.rank, d.local_rank)
     model = HubbardModel(L1=L, L2=L, U=U, beta=float(betas[d.rank]), nt=nt, n_stab=n_stab)
-    eng = engine_factory(model)
+    eng = model.engine(lib, device=d.local_rank)
     eng.set_fields(model.random_fields(seed + d.rank)); eng.init()
     rng = np.random.default_rng(seed + 1000 + d.rank)
-    bern = lambda p: bool(rng.random() < p)
 
     def sweep():
         eng.sweep_0_to_beta(*model.random_stream(rng)); eng.sweep_beta_to_0(*model.random_stream(rng))
 
     for _ in range(therm):
         sweep()
-    eng.sync(); barrier(d)
+    eng.sync(); comm.barrier()
     attempt = accepted = 0
+    t_ex = 0.0
     t0 = time.perf_counter()
     for isweep in range(1, sweeps + 1):
         if isweep % sweep_steps == 0:
-            barrier(d)                                               # MPI_Barrier, source/main.cpp:148
-            attempt, accepted, _ = replica_exchange(d.rank, d.world, bern, attempt, accepted, eng, d.device)
+            comm.barrier()                                            # MPI_Barrier, source/main.cpp:148
+            attempt += 1
+            te = time.perf_counter()
+            res = comm.exchange_round(eng, attempt, float(rng.random()))
+            t_ex += time.perf_counter() - te
+            if d.rank == 0:
+                accepted += res.accepted                               # source/update.cpp:99-101
         sweep()
-    eng.sync(); barrier(d)
-    dt = max_over_ranks(d, time.perf_counter() - t0)
+    eng.sync(); comm.barrier()
+    dt = time.perf_counter() - t0
     st = eng.stats()
-    acc = sum_over_ranks(d, st.n_accepted / max(1, st.n_proposed)) / d.world
+    sums = comm.allreduce_sum([dt, st.n_accepted / max(1, st.n_proposed)])        # the two MPI_Reduce(SUM), source/main.cpp:186-187
     if d.rank == 0:
-        log(f"PT: {d.world} replicas, {sweeps} sweeps in {dt:.2f} s = {d.world * sweeps / dt:.2f} sweeps/s total; "
-            f"acceptance {acc:.4f}; exchange rate {accepted / max(1, attempt):.4f} ({accepted}/{attempt}); "
-            f"max wrap err {st.max_err:.3e}")
+        log(f"PT: {d.world} replicas over {comm.transport}, {sweeps} sweeps in {dt:.2f} s = {d.world * sweeps / dt:.2f} sweeps/s total; "
+            f"acceptance {sums[1] / d.world:.4f}; exchange rate {accepted / max(1, attempt):.4f} ({accepted}/{attempt}), "
+            f"{1e3 * t_ex / max(1, attempt):.1f} ms per round; max wrap err {st.max_err:.3e}")
+    comm.close(); eng.close()
     return sweeps / dt, attempt, accepted
 
 
 def main():
+    from dqmc_amd import CFG4_BETAS, CONFIGS
+    cfg = CONFIGS["cfg4"]
     ap = argparse.ArgumentParser()
-    ap.add_argument("--betas", default="8,7,6,5,4,3.5,3,2.5")
-    ap.add_argument("--L", type=int, default=16)
-    ap.add_argument("--U", type=float, default=8.0)
-    ap.add_argument("--nt", type=int, default=200)
-    ap.add_argument("--n-stab", type=int, default=10)
+    ap.add_argument("--betas", default=",".join(str(b) for b in CFG4_BETAS))
+    ap.add_argument("--L", type=int, default=cfg["L1"])
+    ap.add_argument("--U", type=float, default=cfg["U"])
+    ap.add_argument("--nt", type=int, default=cfg["nt"])
+    ap.add_argument("--n-stab", type=int, default=cfg["n_stab"])
     ap.add_argument("--therm", type=int, default=5)
     ap.add_argument("--sweeps", type=int, default=20)
     ap.add_argument("--sweep-steps", type=int, default=5)
@@ -72,9 +84,8 @@ def main():
     import dqmc_amd
     from dqmc_amd.launch import dist_init, finalize
     d = dist_init()
-    lib = dqmc_amd.lib()
     betas = [float(b) for b in args.betas.split(",") if b.strip()]
-    run_pt(d, lambda m: m.engine(lib, device=d.local_rank), betas, args.L, args.U, args.nt, args.n_stab, args.therm, args.sweeps, args.sweep_steps)
+    run_pt(d, dqmc_amd.lib(), betas, args.L, args.U, args.nt, args.n_stab, args.therm, args.sweeps, args.sweep_steps)
     finalize(d)
 
 

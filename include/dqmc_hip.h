@@ -33,6 +33,7 @@
 #ifndef DQMC_HIP_H
 #define DQMC_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -231,6 +232,66 @@ int dqmc_get_G_tau(dqmc_engine* e, int which, int l, double* out);
  * device-side bin sums instead (out ignored); fetch returns sums and count.           */
 int dqmc_measure_unequal_time(dqmc_engine* e, int L1, int L2, int accumulate, double* out);
 int dqmc_measure_unequal_fetch(dqmc_engine* e, double* out_sum, int64_t* n_measurements, int reset);
+
+/* ---- replica exchange (parallel tempering, BASELINE.json configs[3]) -----------------
+ * The reference runs one inverse temperature per MPI rank and swaps HS-field
+ * configurations between neighbouring ranks with MPI_Sendrecv / MPI_Send / MPI_Recv on
+ * MPI_COMM_WORLD (source/update.cpp:47-117, source/main.cpp:39-67,146-153).  Here a
+ * dqmc_comm plays MPI_COMM_WORLD: one rank per GPU, point-to-point only.
+ *   - RCCL transport: grouped ncclSend/ncclRecv on the engine's stream, HBM to HBM over
+ *     xGMI (4 disjoint pairs per round on 8 GPUs; no ring, no all-reduce on the data path).
+ *     Bootstrap as with NCCL: rank 0 obtains an id (dqmc_comm_unique_id), ships it to the
+ *     other ranks by any means (file, MPI, torch.distributed store), every rank calls
+ *     dqmc_comm_create_rccl.
+ *   - callback transport: the caller supplies an MPI_Sendrecv-shaped function (host
+ *     buffers); used for MPI itself and for in-process replicas (threads).
+ * On the wire a field configuration is the engine's own int8 [nt][n_sites] array
+ * (51 kB at cfg 4; the reference ships nt*nv 64-bit integers, source/update.cpp:60-69).   */
+typedef struct dqmc_comm dqmc_comm;
+#define DQMC_UNIQUE_ID_BYTES 128
+/* blocking pairwise exchange of `bytes` bytes with rank `partner` (both sides call it with
+ * the same bytes and tag); returns 0 on success.  tag: 0 fields, 1 actions, 3 decision,
+ * 4.. collectives.                                                                         */
+typedef int (*dqmc_sendrecv_fn)(void* user, const void* send, void* recv, size_t bytes, int partner, int tag);
+
+int dqmc_comm_unique_id(void* id /* DQMC_UNIQUE_ID_BYTES */);
+int dqmc_comm_create_rccl(dqmc_comm** out, const void* id, int world_size, int rank, int device);
+int dqmc_comm_create_callbacks(dqmc_comm** out, int world_size, int rank, dqmc_sendrecv_fn fn, void* user);
+void dqmc_comm_destroy(dqmc_comm* c);
+int dqmc_comm_rank(dqmc_comm* c);
+int dqmc_comm_world_size(dqmc_comm* c);
+/* "rccl" or "callbacks" */
+const char* dqmc_comm_transport(dqmc_comm* c);
+/* MPI_Barrier (source/main.cpp:148) and the MPI_Reduce(SUM) of source/main.cpp:186-187
+ * (every rank receives the sums).                                                          */
+int dqmc_comm_barrier(dqmc_comm* c);
+int dqmc_comm_allreduce_sum(dqmc_comm* c, double* x, int count);
+
+/* update::partner_rank (source/update.cpp:34-45).                                          */
+int dqmc_partner_rank(int rank, int world_size, int exchange_attempt);
+
+typedef struct dqmc_exchange_result {
+    int    partner;          /* -1: no partner this attempt                                 */
+    int    decider;          /* 1 when this rank drew the decision (rank < partner)          */
+    int    accepted;         /* the pair's decision                                         */
+    int    pad;
+    double S;                /* S_r({s}_r)        (SC,               source/update.cpp:72)  */
+    double S_prime;          /* S_r({s}_partner)  (SC_prime,         :81)                   */
+    double S_partner;        /* SC_partner        (:88-90)                                  */
+    double S_prime_partner;  /* SC_prime_partner  (:84-86)                                  */
+    double deltaS;           /* (S' + S'_partner) - (S + S_partner), :94                    */
+} dqmc_exchange_result;
+
+/* One round of update::replica_exchange (source/update.cpp:47-117) for the single-chain
+ * engine `e` of rank dqmc_comm_rank(comm).  `exchange_attempt` is the counter AFTER the
+ * reference's `exchange_attempt++` (:52); `u` is the canonical uniform that
+ * rng.bernoulli(p) of the deciding rank compares with p (:96, include/utility.h:34-37;
+ * ignored on the rank that does not decide).  Field swap, the trial init_stacks +
+ * init_greenfunctions (:75-80), the two action exchanges, the decision and the restoring
+ * re-initialisation on rejection (:108-115) all happen here; on return G = Gtt[0] and the
+ * stack belong to the fields the engine now holds.  Synchronous.                           */
+int dqmc_replica_exchange_round(dqmc_engine* e, dqmc_comm* comm, int exchange_attempt, double u,
+                                dqmc_exchange_result* result);
 
 /* Number of accepted proposals / kernel time (ms, HIP events on the engine's
  * stream) spent inside the local-update kernels since the last call -- the

@@ -1,0 +1,178 @@
+"""Test plumbing for replica exchange (BASELINE.json configs[3]).
+
+* ``HostPT``: ctypes binding of the in-process parallel-tempering harness of libdqmc_host.so
+  (dqmc_amd/host/host_capi.cpp: W replicas = W threads, each what source/main.cpp builds per MPI rank, engines on the
+  GPU, update::replica_exchange over update::InProcessHub).
+* ``OracleTwin``: the same W replicas on CPU-oracle engines, driven by a plain restatement of
+  source/update.cpp:47-117 and of DQMC::sweep_* 's random-stream consumption, with twin generators
+  (libdqmc_host.so's utility::random) so that every draw matches the harness word for word.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import numpy as np
+
+import dqmc_amd
+from dqmc_amd.abi import ExchangeResult
+
+
+def ini_text(L: int, U: float, nt: int, n_stab: int, beta: float = 1.0) -> str:
+    return (f"[Lattice]\nL1 = {L}\nL2 = {L}\n[hubbard]\nU = {U}\nt = 1.0\nmu = -0.1\n[simulation]\nbeta = {beta}\nnt = {nt}\n"
+            f"n_therms = 0\nn_sweeps = 1\nn_bins = 1\nn_stab = {n_stab}\nsymmetric = false\nisMeasureUnequalTime = false\n")
+
+
+def load_host():
+    h = C.CDLL(dqmc_amd.HOST_LIB_PATH)
+    h.dqmc_host_rng_create.restype = C.c_void_p; h.dqmc_host_rng_create.argtypes = [C.c_uint]
+    h.dqmc_host_rng_destroy.argtypes = [C.c_void_p]
+    h.dqmc_host_rng_next.restype = C.c_uint; h.dqmc_host_rng_next.argtypes = [C.c_void_p]
+    h.dqmc_host_draw_slice.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    h.dqmc_host_rng_bernoulli_uniform.restype = C.c_double; h.dqmc_host_rng_bernoulli_uniform.argtypes = [C.c_void_p]
+    h.dqmc_host_rng_bernoulli.argtypes = [C.c_void_p, C.c_double]
+    h.dqmc_host_model.argtypes = [C.c_char_p, C.c_double, C.c_uint] + [C.c_void_p] * 8 + [C.c_char_p, C.c_int]
+    h.dqmc_host_pt_create.restype = C.c_void_p
+    h.dqmc_host_pt_create.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_int]
+    h.dqmc_host_pt_destroy.argtypes = [C.c_void_p]
+    h.dqmc_host_pt_set_fields.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_char_p, C.c_int]
+    h.dqmc_host_pt_sweeps.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_int]
+    h.dqmc_host_pt_exchange.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_int]
+    h.dqmc_host_pt_get.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 6 + [C.c_char_p, C.c_int]
+    h.dqmc_host_pt_rng_peek.restype = C.c_uint; h.dqmc_host_pt_rng_peek.argtypes = [C.c_void_p, C.c_int]
+    h.dqmc_host_hub_selftest.argtypes = [C.c_int, C.c_int]
+    return h
+
+
+def host_model(h, ini: str, beta: float, seed: int, n: int, nt: int):
+    """AttractiveHubbard's constants and initial fields as the facade builds them (dqmc_host_model)."""
+    ns = C.c_int(0); ntc = C.c_int(0); g = C.c_double(0.0)
+    eK = np.empty((n, n), order="F"); iK = np.empty((n, n), order="F"); f = np.empty(n * nt, np.int64)
+    gam = np.empty(4); eta = np.empty(4); err = C.create_string_buffer(256)
+    rc = h.dqmc_host_model(ini.encode(), beta, seed, C.byref(ns), C.byref(ntc), C.byref(g), eK.ctypes.data, iK.ctypes.data,
+                           f.ctypes.data, gam.ctypes.data, eta.ctypes.data, err, 256)
+    assert rc == 0, err.value
+    assert ns.value == n and ntc.value == nt
+    return dict(g=g.value, expK=eK, invexpK=iK, gamma=gam, eta=eta, fields=f.reshape(n, nt).T.copy())   # fields as (nt, n)
+
+
+class HostPT:
+    def __init__(self, h, ini: str, betas, seeds, devices=None):
+        self.h, self.world = h, len(betas)
+        b = np.ascontiguousarray(betas, np.float64); s = np.ascontiguousarray(seeds, np.uint32)
+        d = np.ascontiguousarray(devices if devices is not None else [0] * self.world, np.int32)
+        self.err = C.create_string_buffer(512)
+        self.p = h.dqmc_host_pt_create(ini.encode(), self.world, b.ctypes.data, s.ctypes.data, d.ctypes.data, self.err, 512)
+        assert self.p, self.err.value
+
+    def _ck(self, rc):
+        assert rc == 0, self.err.value
+
+    def set_fields(self, rank: int, fields):     # fields (nt, n)
+        f = np.ascontiguousarray(np.asarray(fields).T, np.int64)              # nt x nv column-major
+        self._ck(self.h.dqmc_host_pt_set_fields(self.p, rank, f.ctypes.data, self.err, 512))
+
+    def sweeps(self, n: int, concurrently: bool = True):
+        self._ck(self.h.dqmc_host_pt_sweeps(self.p, n, int(concurrently), self.err, 512))
+
+    def exchange(self):
+        res = (ExchangeResult * self.world)()
+        self._ck(self.h.dqmc_host_pt_exchange(self.p, res, self.err, 512))
+        return list(res)
+
+    def get(self, rank: int, n: int, nt: int):
+        f = np.empty(n * nt, np.int64); G = np.empty((n, n), order="F"); ld = C.c_double(0); S = C.c_double(0); a = C.c_int(0); b = C.c_int(0)
+        self._ck(self.h.dqmc_host_pt_get(self.p, rank, f.ctypes.data, G.ctypes.data, C.byref(ld), C.byref(S), C.byref(a), C.byref(b), self.err, 512))
+        return dict(fields=f.reshape(n, nt).T.copy(), G=G, logdet=ld.value, S=S.value, attempt=a.value, accepted=b.value)
+
+    def rng_peek(self, rank: int) -> int:
+        return int(self.h.dqmc_host_pt_rng_peek(self.p, rank))
+
+    def close(self):
+        if self.p:
+            self.h.dqmc_host_pt_destroy(self.p); self.p = None
+
+
+class OracleTwin:
+    """W replicas on oracle engines; restates source/main.cpp:146-157 + source/update.cpp:34-117."""
+
+    def __init__(self, orc, h, ini: str, betas, seeds, n: int, nt: int, n_stab: int):
+        self.h, self.world, self.n, self.nt = h, len(betas), n, nt
+        self.rng = [h.dqmc_host_rng_create(int(s)) for s in seeds]
+        self.eng = []
+        self.attempt = [0] * self.world; self.accepted = [0] * self.world
+        for r in range(self.world):
+            mdl = host_model(h, ini, float(betas[r]), int(seeds[r]), n, nt)
+            e = orc.engine(n, nt, n_stab, mdl["g"], mdl["gamma"], mdl["eta"], mdl["expK"], mdl["invexpK"])
+            e.set_fields(mdl["fields"]); e.init()
+            self.eng.append(e)
+
+    def set_fields(self, rank: int, fields):
+        self.eng[rank].set_fields(fields); self.eng[rank].init()
+
+    def _half_stream(self, rank: int, forward: bool):
+        n, nt = self.n, self.nt
+        perm = np.empty((nt, n), np.int32); k = np.empty((nt, n), np.uint8); u = np.empty((nt, n), np.float64)
+        for step in range(nt):                                     # DQMC::draw_half_sweep: slices in visiting order
+            l = step if forward else nt - 1 - step
+            self.h.dqmc_host_draw_slice(self.rng[rank], n, perm[l].ctypes.data, k[l].ctypes.data, u[l].ctypes.data)
+        return perm, k, u
+
+    def sweeps(self, count: int):
+        for r in range(self.world):
+            for _ in range(count):
+                self.eng[r].sweep_0_to_beta(*self._half_stream(r, True))
+                self.eng[r].sweep_beta_to_0(*self._half_stream(r, False))
+
+    @staticmethod
+    def partner_rank(rank: int, world: int, attempt: int) -> int:   # source/update.cpp:34-45
+        even = attempt % 2 == 0
+        off = (1 if rank % 2 == 0 else -1) if even else (-1 if rank % 2 == 0 else 1)
+        return (rank + off + world) % world
+
+    def exchange(self):
+        """One round for every rank (source/update.cpp:47-117); returns per-rank dicts."""
+        W = self.world
+        out = [None] * W
+        for r in range(W):
+            self.attempt[r] += 1
+        partner = [self.partner_rank(r, W, self.attempt[r]) for r in range(W)]
+        mine = [self.eng[r].get_fields().copy() for r in range(W)]
+        SC = [self.eng[r].global_action() for r in range(W)]
+        SCp = [0.0] * W
+        for r in range(W):                                           # trial state on the partner's fields
+            self.eng[r].set_fields(mine[partner[r]]); self.eng[r].init()
+            SCp[r] = self.eng[r].global_action()
+        for r in range(W):
+            p = partner[r]
+            if r < p:
+                deltaS = (SCp[r] + SCp[p]) - (SC[r] + SC[p])
+                try:
+                    prob = min(1.0, math.exp(-deltaS))
+                except OverflowError:
+                    prob = 1.0
+                acc = bool(self.h.dqmc_host_rng_bernoulli(self.rng[r], prob))     # the real rng.bernoulli(p) of the decider
+                if r == 0:
+                    self.accepted[0] += int(acc)
+                for q in (r, p):
+                    out[q] = dict(partner=partner[q], accepted=acc, S=SC[q], S_prime=SCp[q], S_partner=SC[partner[q]],
+                                  S_prime_partner=SCp[partner[q]], deltaS=deltaS, decider=int(q == r))
+        for r in range(W):
+            if not out[r]["accepted"]:
+                self.eng[r].set_fields(mine[r]); self.eng[r].init()
+        return out
+
+    def get(self, rank: int):
+        e = self.eng[rank]
+        return dict(fields=e.get_fields(), G=e.get_G(), logdet=e.get_logdet(), S=e.global_action(),
+                    attempt=self.attempt[rank], accepted=self.accepted[rank])
+
+    def rng_peek(self, rank: int) -> int:
+        """next raw word of the rank's generator WITHOUT advancing the twin: compared with HostPT.rng_peek."""
+        raise NotImplementedError
+
+    def close(self):
+        for e in self.eng:
+            e.close()
+        for r in self.rng:
+            self.h.dqmc_host_rng_destroy(r)

@@ -1,8 +1,7 @@
-"""world_size-2 tests on CPU (gloo): the one-process-per-GPU plumbing of
-bench.py (barrier, max/sum over ranks) and the replica-exchange round
-(update::replica_exchange, source/update.cpp:47-117) with the CPU oracle
-standing in for the engine -- the transport code is the same that runs over
-RCCL on the GPU node."""
+"""world_size > 1 tests on CPU (gloo): the one-process-per-GPU plumbing of bench.py (rendezvous, barrier, max / sum over
+ranks, the self-launch of `bench.py --gpus N`) and the library's communicator (dqmc_comm_*: barrier, allreduce) across real
+processes with gloo point-to-point as the transport callback.  The exchange round itself needs engines, i.e. a GPU:
+tests/test_gpu_replica.py."""
 import os
 import socket
 
@@ -21,84 +20,57 @@ def _worker(rank, world, port, out_dir):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    from dqmc_amd import HubbardModel
+    import torch.distributed as dist
+    import dqmc_amd
     from dqmc_amd.launch import barrier, dist_init, finalize, max_over_ranks, sum_over_ranks
-    from dqmc_amd.replica import partner_rank, replica_exchange
-    from oracle import oracle
     d = dist_init("gloo")
     assert d.world == world and d.rank == rank
     barrier(d)
     assert max_over_ranks(d, 1.0 + rank) == float(world)
     assert sum_over_ranks(d, 1.0) == float(world)
-    # one beta per rank (source/main.cpp:47-67)
-    betas = [2.0, 1.6]
-    m = HubbardModel(L1=4, L2=4, U=4.0, beta=betas[rank], nt=20, n_stab=10)
-    e = m.engine(oracle()); f0 = m.random_fields(100 + rank); e.set_fields(f0); e.init()
-    S_own = e.global_action()
-    log = []
-    attempt, accepted = 0, 0
-    for rnd, force in enumerate([True, False, None]):
-        before = e.get_fields().copy()
-        if force is None:
-            rng = np.random.default_rng(5)
-            bern = lambda p: bool(rng.random() < p)
-        else:
-            bern = lambda p, force=force: force
-        attempt, accepted, acc = replica_exchange(rank, world, bern, attempt, accepted, e, d.device)
-        after = e.get_fields()
-        log.append(dict(round=rnd, acc=bool(acc), same=bool((after == before).all()), before=before, after=after,
-                        partner=partner_rank(rank, world, attempt), S=e.global_action(), G=e.get_G()))
-    np.save(os.path.join(out_dir, f"rank{rank}.npy"), np.array(log, dtype=object), allow_pickle=True)
-    np.save(os.path.join(out_dir, f"f0_{rank}.npy"), f0)
-    assert abs(S_own - S_own) == 0.0
+    # the library's communicator (include/dqmc_hip.h) with gloo point-to-point as the MPI_Sendrecv callback: its barrier and
+    # allreduce are what the C++ driver calls at source/main.cpp:148,186-187
+    lib = dqmc_amd.lib()
+
+    def sendrecv(send: bytes, partner: int, tag: int) -> bytes:
+        t_send = torch.frombuffer(bytearray(send), dtype=torch.uint8); t_recv = torch.empty_like(t_send)
+        ops = [dist.P2POp(dist.isend, t_send, partner), dist.P2POp(dist.irecv, t_recv, partner)]
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+        return t_recv.numpy().tobytes()
+    comm = lib.comm_callbacks(world, rank, sendrecv)
+    comm.barrier()
+    got = comm.allreduce_sum([1.0 + rank, 0.5])
+    assert got.tolist() == [world * (world + 1) / 2.0, 0.5 * world]
+    assert lib.partner_rank(rank, world, 1) == (rank + (-1 if rank % 2 == 0 else 1) + world) % world
+    comm.barrier(); comm.close()
+    np.save(os.path.join(out_dir, f"ok{rank}.npy"), got)
     finalize(d)
 
 
-def test_two_rank_replica_exchange_over_gloo(tmp_path):
-    world = 2
+@pytest.mark.parametrize("world", [2, 4])
+def test_library_communicator_across_processes_over_gloo(tmp_path, world):
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
-    logs = [np.load(tmp_path / f"rank{r}.npy", allow_pickle=True) for r in range(world)]
-    f0 = [np.load(tmp_path / f"f0_{r}.npy") for r in range(world)]
-    # round 0: forced accept -> the two ranks hold each other's fields
-    assert logs[0][0]["acc"] and logs[1][0]["acc"]
-    assert (logs[0][0]["after"] == f0[1]).all() and (logs[1][0]["after"] == f0[0]).all()
-    # round 1: forced reject -> nothing changes, both ranks agree
-    assert not logs[0][1]["acc"] and not logs[1][1]["acc"] and logs[0][1]["same"] and logs[1][1]["same"]
-    # round 2: Metropolis decision taken by the lower rank, shared with the partner
-    assert logs[0][2]["acc"] == logs[1][2]["acc"]
-    if logs[0][2]["acc"]:
-        assert (logs[0][2]["after"] == logs[1][2]["before"]).all() and (logs[1][2]["after"] == logs[0][2]["before"]).all()
     for r in range(world):
-        for rec in logs[r]:
-            assert rec["partner"] == 1 - r
-    # G after a round equals a from-scratch evaluation of the fields the rank ended with
-    from dqmc_amd import HubbardModel
-    from oracle import oracle
-    for r, beta in enumerate([2.0, 1.6]):
-        m = HubbardModel(L1=4, L2=4, U=4.0, beta=beta, nt=20, n_stab=10)
-        e = m.engine(oracle()); e.set_fields(logs[r][2]["after"]); e.init()
-        assert np.abs(e.get_G() - logs[r][2]["G"]).max() < 1e-12
+        assert os.path.exists(tmp_path / f"ok{r}.npy")
 
 
-def _pt_worker(rank, world, port, out_dir):
-    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    import sys
-    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    from dqmc_amd.launch import dist_init, finalize
-    from dqmc_amd.pt_run import run_pt
-    from oracle import oracle
-    d = dist_init("gloo")
-    lines = []
-    rate, attempt, accepted = run_pt(d, lambda m: m.engine(oracle()), [2.0, 1.8], L=4, U=4.0, nt=20, n_stab=10, therm=1, sweeps=6,
-                                     sweep_steps=2, log=lines.append)
-    with open(os.path.join(out_dir, f"pt{rank}.txt"), "w") as fh:
-        fh.write(f"{attempt} {accepted} {rate}\n" + "\n".join(lines))
-    finalize(d)
-
-
-def test_parallel_tempering_driver_two_ranks(tmp_path):
-    """The cfg-4 driver loop (barrier + replica_exchange every sweep_steps sweeps) end to end on gloo."""
-    mp.spawn(_pt_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
-    a0 = open(tmp_path / "pt0.txt").read().split("\n"); a1 = open(tmp_path / "pt1.txt").read().split("\n")
-    assert a0[0].split()[0] == "3" and a1[0].split()[0] == "3"          # 6 sweeps, exchange every 2nd
-    assert "exchange rate" in a0[1] and a1[1:] == [""]                     # only rank 0 reports (source/main.cpp:204)
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus N` without a launcher spawns N fresh rank processes itself (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* set), rank 0 prints the one JSON line with n_gpus = N; a launcher whose WORLD_SIZE disagrees with --gpus, or too
+    few visible devices, is an error -- never a silent N = 1 run."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check"], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    rec = json.loads(lines[0])
+    assert rec == {"launch_check": True, "n_gpus": 2, "max_over_ranks": 2.0, "backend": "gloo"}
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check"], capture_output=True, text=True, timeout=600,
+                         env=dict(env, WORLD_SIZE="4", RANK="0"))
+    assert bad.returncode == 2 and "does not match WORLD_SIZE" in bad.stderr
+    if torch.cuda.device_count() < 2:
+        few = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=600, env=env)
+        assert few.returncode == 2 and "GPU(s) visible" in few.stderr and not few.stdout.strip()

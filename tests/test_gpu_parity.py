@@ -13,6 +13,8 @@ import os
 import numpy as np
 import pytest
 
+import golden_util
+
 from dqmc_amd import CONFIGS, HubbardModel
 from oracle.numpy_ref import free_fermion_G
 
@@ -542,19 +544,21 @@ def test_error_codes(hip):
         e.set_fields(bad)
 
 
-@pytest.mark.parametrize("name", sorted(fn[:-4] for fn in os.listdir(GOLD) if fn.endswith(".npz")) if os.path.isdir(GOLD) else [])
+@pytest.mark.parametrize("name", golden_util.NAMES)
 def test_golden_vectors(hip, name):
-    z = np.load(os.path.join(GOLD, name + ".npz"))
-    m = HubbardModel(L1=int(z["L1"]), L2=int(z["L2"]), U=float(z["U"]), beta=float(z["beta"]), nt=int(z["nt"]), n_stab=int(z["n_stab"]))
+    z, m, streams = golden_util.load(name)
     e = m.engine(hip); e.set_fields(z["fields"]); e.init()
-    err = np.abs(e.get_G() - z["G0"]).max(); scale = max(1.0, np.abs(z["G0"]).max())
+    err, scale = golden_util.g0_error(z, e.get_G())
     print(f"{name}: max|dG| = {err:.3e} (max|G| = {scale:.3e}, tol {float(z['tol']):.0e})")
     assert err <= float(z["tol"]) * scale
     assert abs(e.get_logdet() - float(z["logdet"])) < 1e-8 * max(1.0, abs(float(z["logdet"])))
-    if "G_after" in z.files:
-        e.sweep_0_to_beta(z["perm_f"], z["k_f"], z["u_f"]); e.sweep_beta_to_0(z["perm_b"], z["k_b"], z["u_b"])
+    if streams is not None:
+        e.sweep_0_to_beta(*streams[0]); e.sweep_beta_to_0(*streams[1])
         assert (e.get_fields() == z["fields_after"]).all()
-        assert np.abs(e.get_G() - z["G_after"]).max() <= float(z["tol"]) * max(1.0, np.abs(z["G_after"]).max())
+        errA = np.abs(e.get_G() - z["G_after"]).max(); scaleA = max(1.0, np.abs(z["G_after"]).max())
+        print(f"{name}: after sweep max|dG| = {errA:.3e} (max|G| = {scaleA:.3e})")
+        assert errA <= float(z["tol"]) * scaleA
+        assert e.stats().n_accepted == int(z["n_accepted"])
 
 
 # ---- the main.cpp-shaped driver writes results/ in the reference's on-disk format -------------------

@@ -1,0 +1,155 @@
+"""GPU tests (-m gpu) of replica exchange, BASELINE.json configs[3] (cfg 4: 16x16 Hubbard, 8 inverse temperatures):
+HIP engines driven through update::replica_exchange of the host facade (dqmc_amd/host/dqmc_host.hpp) and through the
+C ABI (dqmc_replica_exchange_round) with in-process transports, against CPU-oracle engines fed with the same random
+streams (tests/pt_twin.py restates source/update.cpp:34-117).  Decisions, partners, counters and exchanged fields must
+match exactly; the actions S, S' to 1e-8 relative; G after acceptance / after the restoring re-initialisation to
+1e-10 * max(1, max|G|).  The RCCL transport itself needs one GPU per rank (RCCL refuses two ranks on one device), so on
+the one-GPU box the wire is the callback transport; bench.py exercises the RCCL path when it runs on N > 1 GPUs."""
+import os
+import re
+import subprocess
+import threading
+
+import numpy as np
+import pytest
+
+import dqmc_amd
+from dqmc_amd import CONFIGS, HubbardModel
+
+from pt_twin import HostPT, OracleTwin, ini_text, load_host
+from test_replica import PyHub
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+
+
+def _compare_round(tag, res, ref, pt, tw, n, nt):
+    W = len(ref)
+    for r in range(W):
+        a, b = res[r], ref[r]
+        assert a.partner == b["partner"], (tag, r)
+        assert bool(a.accepted) == bool(b["accepted"]), (tag, r, a.deltaS, b["deltaS"])
+        assert a.decider == b["decider"]
+        for got, want in ((a.S, b["S"]), (a.S_prime, b["S_prime"]), (a.S_partner, b["S_partner"]), (a.S_prime_partner, b["S_prime_partner"])):
+            assert abs(got - want) <= 1e-8 * max(1.0, abs(want)), (tag, r, got, want)
+        assert abs(a.deltaS - b["deltaS"]) <= 1e-6 * max(1.0, abs(b["deltaS"])) + 1e-8 * max(abs(b["S"]), abs(b["S_prime"]))
+        g, o = pt.get(r, n, nt), tw.get(r)
+        assert np.array_equal(g["fields"], o["fields"]), (tag, r)
+        scale = max(1.0, np.abs(o["G"]).max())
+        err = np.abs(g["G"] - o["G"]).max()
+        assert err <= TOL * scale, (tag, r, err, scale)
+        assert abs(g["logdet"] - o["logdet"]) <= 1e-9 * max(1.0, abs(o["logdet"]))
+        assert (g["attempt"], g["accepted"]) == (o["attempt"], o["accepted"])
+
+
+def test_cfg4_replica_exchange_on_hip_engines(hip, orc):
+    """8 HIP engines at 8 betas (16x16, U = 8, Ltau = 200) on one GPU, 4 exchange rounds (odd attempt with the 0 <-> 7 wrap,
+    even attempt, odd again, one more after a full sweep of every replica) through update::replica_exchange."""
+    cfg = CONFIGS["cfg4"]; L, U, nt, n_stab = cfg["L1"], cfg["U"], cfg["nt"], cfg["n_stab"]; n = L * L
+    betas = [8.0, 7.9, 7.0, 6.9, 6.0, 5.9, 5.0, 4.9]          # near pairs: probabilistic decisions; far pairs: forced rejections
+    seeds = [1000 + r for r in range(8)]
+    ini = ini_text(L, U, nt, n_stab)
+    h = load_host()
+    orc.set_backend("lapack")                                 # MKL dgeqp3 / dgetrf when present (what the reference links); built-in otherwise
+    pt = HostPT(h, ini, betas, seeds); tw = OracleTwin(orc, h, ini, betas, seeds, n, nt, n_stab)
+    try:
+        for r in range(8):                                    # same initial fields on both sides (GHQField's by-value generator copy)
+            assert np.array_equal(pt.get(r, n, nt)["fields"], tw.get(r)["fields"])
+        seen = set()
+        for rnd in range(3):
+            res, ref = pt.exchange(), tw.exchange()
+            _compare_round(f"round {rnd}", res, ref, pt, tw, n, nt)
+            seen |= {(rnd % 2, bool(x["accepted"])) for x in ref}
+            if rnd == 0:
+                assert res[0].partner == 7 and res[7].partner == 0 and res[0].decider == 1        # the wrap pair, rank 0 decides
+        assert {True, False} <= {a for _, a in seen}, "both an accepted and a rejected swap must occur"
+        pt.sweeps(1, concurrently=True); tw.sweeps(1)          # 8 engines sweeping at once on one device
+        for r in range(8):
+            g, o = pt.get(r, n, nt), tw.get(r)
+            assert np.array_equal(g["fields"], o["fields"]), r
+            assert np.abs(g["G"] - o["G"]).max() <= TOL * max(1.0, np.abs(o["G"]).max())
+        res, ref = pt.exchange(), tw.exchange()
+        _compare_round("round 3 (after a sweep)", res, ref, pt, tw, n, nt)
+        for r in range(8):                                    # generators advanced identically (only deciders drew, two words each)
+            assert pt.rng_peek(r) == h.dqmc_host_rng_next(tw.rng[r]), r
+    finally:
+        pt.close(); tw.close(); orc.set_backend("builtin")
+
+
+def test_exchange_round_through_the_c_abi(hip, orc):
+    """dqmc_replica_exchange_round called directly (ctypes) by two ranks = two Python threads with a Python
+    MPI_Sendrecv callback; a forced accept (u = 0) and a forced reject (u = 1 - eps with deltaS > 0)."""
+    betas = [2.0, 1.6]
+    models = [HubbardModel(L1=4, L2=4, U=4.0, beta=b, nt=20, n_stab=10) for b in betas]
+    f0 = [models[r].random_fields(100 + r) for r in range(2)]
+    hub = PyHub(); results = {}; errs = []
+    eng = [models[r].engine(hip) for r in range(2)]
+    ref = [models[r].engine(orc) for r in range(2)]
+    for r in range(2):
+        for e in (eng[r], ref[r]):
+            e.set_fields(f0[r]); e.init()
+
+    def run(r, attempt, u):
+        try:
+            c = hip.comm_callbacks(2, r, hub.endpoint(r))
+            results[(r, attempt)] = c.exchange_round(eng[r], attempt, u)
+            c.close()
+        except Exception as e:                      # noqa: BLE001
+            errs.append((r, repr(e)))
+
+    def both(attempt, u):
+        th = [threading.Thread(target=run, args=(r, attempt, u)) for r in range(2)]
+        [t.start() for t in th]; [t.join(300) for t in th]
+        assert not errs, errs
+        return results[(0, attempt)], results[(1, attempt)]
+
+    # reference values of the four actions
+    S = [ref[r].global_action() for r in range(2)]
+    Sp = []
+    for r in range(2):
+        ref[r].set_fields(f0[1 - r]); ref[r].init(); Sp.append(ref[r].global_action())
+    dS = (Sp[0] + Sp[1]) - (S[0] + S[1])
+    a0, a1 = both(1, 0.0)                                     # u = 0 < p: accepted whatever deltaS is
+    assert (a0.partner, a1.partner, a0.decider, a1.decider) == (1, 0, 1, 0)
+    assert a0.accepted == 1 and a1.accepted == 1
+    for r, a in enumerate((a0, a1)):
+        assert abs(a.S - S[r]) < 1e-9 * abs(S[r]) and abs(a.S_prime - Sp[r]) < 1e-9 * abs(Sp[r])
+        assert abs(a.S_partner - S[1 - r]) < 1e-9 * abs(S[r]) and abs(a.deltaS - dS) < 1e-7
+        assert np.array_equal(eng[r].get_fields(), f0[1 - r])                    # swapped
+        assert np.abs(eng[r].get_G() - ref[r].get_G()).max() < TOL               # ref[r] holds the partner's fields too
+    # now swap back with a decision that must fail: fields are exchanged again, deltaS' = -dS; pick u to reject
+    b0, b1 = both(2, 1.0 - 1e-12 if -dS > 0 else 2.0)
+    assert b0.accepted == 0 and b1.accepted == 0
+    for r in range(2):
+        assert np.array_equal(eng[r].get_fields(), f0[1 - r])                    # restored = still the swapped configuration
+        assert np.abs(eng[r].get_G() - ref[r].get_G()).max() < TOL
+    for e in eng + ref:
+        e.close()
+
+
+def test_driver_parallel_tempering_in_process(hip, tmp_path):
+    """dqmc_driver with [ParallelTempering] enabled = true and no launcher: one thread per beta on the visible GPU,
+    swaps through update::InProcessHub (source/main.cpp:39-67,146-153,203-208)."""
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    driver = os.path.join(here, "dqmc_amd", "dqmc_driver")
+    ini = ("[Lattice]\nL1 = 4\nL2 = 4\n[hubbard]\nU = 4.0\nt = 1.0\nmu = -0.1\n[simulation]\nbeta = 2.0\nnt = 20\nn_therms = 3\nn_sweeps = 4\n"
+           "n_bins = 2\nn_stab = 10\nsymmetric = false\nisMeasureUnequalTime = false\n[ParallelTempering]\nenabled = true\nsweep_steps = 2\n"
+           "betas = 2.0, 1.9, 1.8, 1.7\n")
+    (tmp_path / "parameters.in").write_text(ini)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    out = subprocess.run([driver, "parameters.in", "0", "4242"], cwd=tmp_path, capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:] + out.stdout[-2000:]
+    assert "Parallel Tempering enabled, 4 rank(s), transport callbacks" in out.stdout, out.stdout
+    m = re.search(r"Parallel tempering exchange rate = ([\d.]+) \((\d+)/(\d+)\)", out.stdout)
+    assert m and int(m.group(3)) == 4, out.stdout                 # 8 sweeps, exchange every 2
+    assert 0 <= int(m.group(2)) <= 4
+    for r in range(4):
+        assert re.search(rf"rank {r}: device 0, beta {[2, 1.9, 1.8, 1.7][r]}", out.stdout), out.stdout
+        assert len(re.findall(rf"rank {r} bin \d+ \(4 sweeps\)", out.stdout)) == 2
+    # the reference's two MPI_Abort checks (source/main.cpp:52-62)
+    (tmp_path / "parameters.in").write_text(ini.replace("betas = 2.0, 1.9, 1.8, 1.7", "betas = 2.0, 1.9, 1.8"))
+    out = subprocess.run([driver, "parameters.in", "0", "4242"], cwd=tmp_path, capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 1 and "need to be even" in out.stderr
+    env2 = dict(env, RANK="0", WORLD_SIZE="2", LOCAL_RANK="0")
+    out = subprocess.run([driver, "parameters.in", "0", "4242"], cwd=tmp_path, capture_output=True, text=True, timeout=300, env=env2)
+    assert out.returncode == 1 and "must match the number of MPI processes" in out.stderr

@@ -9,7 +9,10 @@ import pytest
 
 import dqmc_amd
 from dqmc_amd import CONFIGS, HubbardModel
-from dqmc_amd.replica import partner_rank
+
+
+def partner_rank(rank, world, attempt):
+    return dqmc_amd.lib().partner_rank(rank, world, attempt)
 
 
 @pytest.fixture(scope="module")

@@ -7,6 +7,8 @@ import os
 import numpy as np
 import pytest
 
+import golden_util
+
 from dqmc_amd import CONFIGS, HubbardModel
 from oracle.numpy_ref import NumpyChain, free_fermion_G
 import oracle.numpy_ref as nr
@@ -122,20 +124,29 @@ def test_short_last_block(orc):
     assert (e.get_fields() == c.f).all() and np.abs(e.get_G() - c.G).max() < 1e-10
 
 
-@pytest.mark.parametrize("name", sorted(fn[:-4] for fn in os.listdir(GOLD) if fn.endswith(".npz")) if os.path.isdir(GOLD) else [])
+@pytest.mark.parametrize("name", golden_util.NAMES)
 def test_golden_vectors(orc, name):
     """Committed fixtures (tests/golden/make_golden.py): inputs + outputs of the
-    numpy/scipy evaluation; the oracle must reproduce them."""
-    z = np.load(os.path.join(GOLD, name + ".npz"))
-    m = HubbardModel(L1=int(z["L1"]), L2=int(z["L2"]), U=float(z["U"]), beta=float(z["beta"]), nt=int(z["nt"]), n_stab=int(z["n_stab"]))
-    e = m.engine(orc); e.set_fields(z["fields"]); e.init()
-    scale = max(1.0, np.abs(z["G0"]).max())
-    assert np.abs(e.get_G() - z["G0"]).max() < float(z["tol"]) * scale
-    assert abs(e.get_logdet() - float(z["logdet"])) < 1e-8 * max(1.0, abs(float(z["logdet"])))
-    if "G_after" in z.files:
-        e.sweep_0_to_beta(z["perm_f"], z["k_f"], z["u_f"]); e.sweep_beta_to_0(z["perm_b"], z["k_b"], z["u_b"])
-        assert (e.get_fields() == z["fields_after"]).all()
-        assert np.abs(e.get_G() - z["G_after"]).max() < float(z["tol"]) * max(1.0, np.abs(z["G_after"]).max())
+    numpy/scipy evaluation; the oracle must reproduce them (both dense back ends)."""
+    z, m, streams = golden_util.load(name)
+    backends = ["builtin"] + (["lapack"] if orc.set_backend("lapack") else [])
+    try:
+        for be in backends:
+            orc.set_backend(be)
+            e = m.engine(orc); e.set_fields(z["fields"]); e.init()
+            err, scale = golden_util.g0_error(z, e.get_G())
+            assert err < float(z["tol"]) * scale, (be, err, scale)
+            assert abs(e.get_logdet() - float(z["logdet"])) < 1e-8 * max(1.0, abs(float(z["logdet"])))
+            if streams is not None and (m.n <= 64 or be == "lapack" or len(backends) == 1):      # the built-in kernels take ~25 s for a cfg-3 sweep
+                e.sweep_0_to_beta(*streams[0]); e.sweep_beta_to_0(*streams[1])
+                assert (e.get_fields() == z["fields_after"]).all()
+                errA = np.abs(e.get_G() - z["G_after"]).max(); scaleA = max(1.0, np.abs(z["G_after"]).max())
+                print(f"{name} [{be}]: init {err:.2e} / {scale:.2e}, after sweep {errA:.2e} / {scaleA:.2e}")
+                assert errA < float(z["tol"]) * scaleA, (be, errA, scaleA)
+                assert e.stats().n_accepted == int(z["n_accepted"])
+            e.close()
+    finally:
+        orc.set_backend("builtin")
 
 
 # ---- SURVEY.md 8(f) row 1: equal-time observables -------------------------------------------------------------
