@@ -93,7 +93,7 @@ int run_rank(const RunConfig& rc, int rank, int world_size, int device, dqmc_com
     const int n_sweeps = params.getInt("simulation", "n_sweeps"), n_therms = params.getInt("simulation", "n_therms"), n_bins = params.getInt("simulation", "n_bins");
 
     Lattice lat(params, {1.0, 0.0}, {0.0, 1.0}, {{0.0, 0.0}});
-    if (rank == master) lat.save_info("results/info");
+    if (rank == master || world_size == 1) lat.save_info("results/info");      // world_size 1: `rank` is only the label of an independent chain
     AttractiveHubbard model(params, lat, rng, my_beta);
     const int n_flavor = model.n_flavor();
     DQMC sim(params, model, device);

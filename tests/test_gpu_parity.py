@@ -208,15 +208,22 @@ def test_cfg3_one_block_then_properties(hip, orc):
     G0 = o.get_G(); scale = np.abs(G0).max()
     assert np.abs(e.get_G() - G0).max() <= TOL * scale
     rng = np.random.default_rng(4)
+    # a second CPU evaluation (the oracle's LAPACK back end when present) of the same ten slices gives the floor for the
+    # comparison BETWEEN stabilisations: ten unstabilised wraps from random fields amplify rounding differences (the reference's
+    # own wrap error here is ~1e-6, source/dqmc.cpp:390), in either code alone exactly as between the two
+    have_lapack = orc.set_backend("lapack")
+    o2 = m.engine(orc); o2.set_fields(f); o2.init()
+    orc.set_backend("builtin")
     for l in range(10):
         s = m.random_stream(rng, 1)
-        e.wrap_forward(l); o.wrap_forward(l)
-        assert e.local_update_slice(l, *s) == o.local_update_slice(l, *s)
+        e.wrap_forward(l); o.wrap_forward(l); o2.wrap_forward(l)
+        acc = o.local_update_slice(l, *s)
+        assert e.local_update_slice(l, *s) == acc and o2.local_update_slice(l, *s) == acc
     assert (e.get_fields() == o.get_fields()).all()
-    # ten UNstabilised wraps from random fields amplify the 1e-8 starting difference exactly as they
-    # amplify rounding inside either code alone (the reference's own wrap error here is ~1e-6,
-    # source/dqmc.cpp:390): compare loosely here, tightly at the stabilised points below
-    assert np.abs(e.get_G() - o.get_G()).max() <= 1e-6 * max(1.0, np.abs(o.get_G()).max())
+    floor = np.abs(o2.get_G() - o.get_G()).max() if have_lapack else 0.0
+    d10 = np.abs(e.get_G() - o.get_G()).max()
+    print(f"cfg3 after 10 unstabilised wraps: GPU-vs-CPU {d10:.3e}, CPU-vs-CPU {floor:.3e}, max|G| = {np.abs(o.get_G()).max():.3e}")
+    assert d10 <= max(3.0 * floor, TOL * max(1.0, np.abs(o.get_G()).max())) if have_lapack else d10 <= 1e-6 * max(1.0, np.abs(o.get_G()).max())
     # one full forward sweep against the oracle: exact fields, stabilised G
     ef = m.engine(hip); ef.set_fields(f); ef.init(); of = m.engine(orc); of.set_fields(f); of.init()
     sf = m.random_stream(rng)
@@ -224,7 +231,7 @@ def test_cfg3_one_block_then_properties(hip, orc):
     assert (ef.get_fields() == of.get_fields()).all()
     d = np.abs(ef.get_G() - of.get_G()).max()
     print(f"cfg3 forward sweep: max|dG| = {d:.3e}, max|G| = {np.abs(of.get_G()).max():.3e}, acc = {ef.stats().n_accepted}")
-    assert d <= 1e-9 * max(1.0, np.abs(of.get_G()).max())
+    assert d <= TOL * max(1.0, np.abs(of.get_G()).max())
     assert ef.stats().n_accepted == of.stats().n_accepted
     # full sweep with every proposal rejected: G(beta,beta) = G(0,0), fields untouched,
     # wrap-vs-stabilised error below the reference's alarm threshold (source/dqmc.cpp:390)
@@ -259,7 +266,7 @@ def test_cfg5_size_streaming_kernels(hip, orc):
         Go = o.get_G(); scale = max(1.0, np.abs(Go).max())
         err = np.abs(e.get_G() - Go).max()
         print(f"cfg5 init: max|dG| = {err:.3e}, max|G| = {scale:.3e}, lapack oracle = {fast}")
-        assert err <= 1e-9 * scale
+        assert err <= TOL * scale
         assert abs(e.get_logdet() - o.get_logdet()) < 1e-9 * abs(o.get_logdet())
         rng = np.random.default_rng(6)
         for l in range(3):
@@ -267,7 +274,9 @@ def test_cfg5_size_streaming_kernels(hip, orc):
             e.wrap_forward(l); o.wrap_forward(l)
             assert e.local_update_slice(l, *s) == o.local_update_slice(l, *s)
         assert (e.get_fields() == o.get_fields()).all()
-        assert np.abs(e.get_G() - o.get_G()).max() <= 1e-7 * max(1.0, np.abs(o.get_G()).max())
+        d3 = np.abs(e.get_G() - o.get_G()).max(); s3 = max(1.0, np.abs(o.get_G()).max())
+        print(f"cfg5 after 3 unstabilised wraps: max|dG| = {d3:.3e}, max|G| = {s3:.3e}")
+        assert d3 <= 10 * TOL * s3                    # between stabilisations (three wraps from i.i.d. fields): one decade above the stabilised-point bar
     finally:
         orc.set_backend("builtin")
     # one full sweep: exercises every stabilisation path at this size; consistency with a from-scratch evaluation
@@ -433,6 +442,8 @@ def test_observables_batched_and_golden(hip):
         assert np.abs(scb[c] - s1).max() < 1e-12 and np.abs(chib[c] - c1).max() < 1e-12
     for name in sorted(fn[:-4] for fn in os.listdir(GOLD) if fn.endswith(".npz")):
         z = np.load(os.path.join(GOLD, name + ".npz"))
+        if "G0_rows" in z.files:
+            continue                                  # cfg 5 stores a row subset of G(0,0): no full matrix to evaluate the observables on
         mg = HubbardModel(L1=int(z["L1"]), L2=int(z["L2"]), U=float(z["U"]), beta=float(z["beta"]), nt=int(z["nt"]), n_stab=int(z["n_stab"]))
         e = mg.engine(hip); e.set_fields(z["fields"]); e.init()
         sc, chi = e.measure_equal_time(mg.L1, mg.L2)
@@ -442,10 +453,10 @@ def test_observables_batched_and_golden(hip):
 
 
 # ---- unequal-time path on the device -------------------------------------------------------
-@pytest.mark.parametrize("cfg,tol", [("cfg1", 1e-10), ("cfg2", 1e-10), ("cfg3", 1e-9)])
+@pytest.mark.parametrize("cfg,tol", [("cfg1", 1e-10), ("cfg2", 1e-10), ("cfg3", 1e-10)])
 def test_unequal_time_parity(hip, orc, cfg, tol):
-    """Gtt[l], Gt0[l], G0t[l] for every slice after one sweep on both sides, device vs oracle (fp64; cfg 3 is held to 1e-9 of the
-    largest entry: 200 slices of propagation between 20 stabilisations), plus the three wrap errors per stabilisation in the stats."""
+    """Gtt[l], Gt0[l], G0t[l] for every slice after one sweep on both sides, device vs oracle (fp64, 1e-10 of the largest entry of the
+    slice at every size: measured 4e-11 / 4e-12 / 6e-11 at cfg 1 / 2 / 3), plus the three wrap errors per stabilisation in the stats."""
     m = HubbardModel(**CONFIGS[cfg]); rng = np.random.default_rng(6)
     f0 = m.random_fields(17); sf, sb = m.random_stream(rng), m.random_stream(rng)
     e = m.engine(hip); o = m.engine(orc)
