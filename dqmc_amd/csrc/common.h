@@ -107,11 +107,12 @@ int launch_fold_stats(DevStats* st, const int* acc, long acc_stride, int n_slice
 struct QrWork {
     double* tau; long tau_stride;      // n per chain
     int* jpvt; long jpvt_stride;       // n per chain
-    unsigned long long* sync = nullptr; long sync_stride = 0;   // cooperative QRCP: granule records, >= qrcp_coop_sync_granules() per chain
+    unsigned long long* sync = nullptr; long sync_stride = 0;   // cooperative QRCP: granule records, >= qrcp_coop_sync_granules(n) per chain
     int* abort_words = nullptr;                                 // cooperative QRCP: one word per chain
     int* info = nullptr;                                        // |= 2 when a cooperative factorisation gave up waiting
 };
-long qrcp_coop_sync_granules();
+long qrcp_coop_sync_granules(int n);        // granules of cooperative-QRCP workspace per chain
+int qrcp_coop_workgroups(int n, int n_chains);
 int launch_to_ldr(Mat A, Mat L, Vec d, Mat R, QrWork w, int n, int n_chains, hipStream_t s);
 
 // ---- lu.hip -----------------------------------------------------------------
@@ -153,6 +154,7 @@ struct UpdateDesc {
     const UpdateTables* tabs;                 // [chain]
     const int32_t* perm; const uint8_t* kprop; const double* u; long rs_stride;  // random stream [chain][nt][n]
     double* Upanel; double* Wpanel; long panel_stride;   // [chain][KD][n]
+    double* Cpanel = nullptr;                 // [chain][KD][KD]: the window's k x k matrix of the sub-matrix walk (update_sm.hip); null -> delayed-update walk
     int* state; long state_stride;            // per chain: [0]=pos, [1]=k (accepts in current window), [2]=accepted in slice
     double* prep; long prep_stride;           // per chain 4*n doubles: the slice's G-independent proposal data
     Mat GT{nullptr, 0};                       // transposed copy of G the n <= 256 walk reads rows from; kept in step by the flushes
@@ -165,6 +167,8 @@ struct UpdateDesc {
 constexpr int UPDATE_KD = 32;    // delayed-update window (accepted flips per flush)
 // one slice = reset + windows x (scan kernel, flush kernel)
 int launch_update_slice(const UpdateDesc& d, int l, int acc_slot, int n_chains, hipStream_t s);
+// sub-matrix variant of the persistent single-launch slice kernel (update_sm.hip)
+int launch_update_slice_sm(const UpdateDesc& d, int l, int acc_slot, int n_chains, hipStream_t s);
 // CU reservation for the persistent single-launch slice kernel (see update.hip); an engine that holds one passes slice_sync
 bool slice_reserve(int device, int n, int n_chains);
 void slice_release(int device, int n, int n_chains);
@@ -173,9 +177,9 @@ int launch_rank1(Mat G, int i, double delta, double* scratch /*2n+1 doubles per 
 
 // ---- per-device kernel attributes (dynamic LDS > 64 KiB), set once per device by init_device_kernels (engine.hip) ----
 int update_init_device();
+int update_sm_init_device();
 int qr_init_device();
 int qr_colown_init_device();
-int qr_onchip_init_device();
 int init_device_kernels(int device);
 
 // ---- engine.hip internals replica.hip needs: the HBM-resident HS fields of a single-chain engine ----

@@ -37,7 +37,7 @@ int init_device_kernels(int device) {
     if (device < 0 || device >= 64) { set_error("device ordinal out of range"); return -1; }
     if (done[device]) return 0;
     DQ_HIP(hipSetDevice(device));
-    DQ_TRY(update_init_device()); DQ_TRY(qr_init_device()); DQ_TRY(qr_colown_init_device()); DQ_TRY(qr_onchip_init_device());
+    DQ_TRY(update_init_device()); DQ_TRY(update_sm_init_device()); DQ_TRY(qr_init_device()); DQ_TRY(qr_colown_init_device());
     done[device] = true;
     return 0;
 }
@@ -84,7 +84,7 @@ struct Ctx {
         DQ_HIP(hipMalloc(&vpool, sizeof(double) * 8 * C * n));
         DQ_HIP(hipMalloc(&ipool, sizeof(int) * (3L * C * n + 4)));
         DQ_HIP(hipMalloc(&spool, sizeof(double) * 4 * C));
-        DQ_HIP(hipMalloc(&qsync, sizeof(unsigned long long) * qrcp_coop_sync_granules() * C));
+        DQ_HIP(hipMalloc(&qsync, sizeof(unsigned long long) * qrcp_coop_sync_granules(n) * C));
         DQ_HIP(hipMalloc(&qabort, sizeof(int) * C));
         DQ_HIP(hipMalloc(&tinv, sizeof(double) * 2048 * C));
         // latency regime only: with many chains per launch the blocked LU + per-column substitution has the higher throughput
@@ -115,7 +115,7 @@ struct Ctx {
     int to_ldr(Mat A, LdrRef out, bool direct = true) {
         const bool keep = direct && out.jpvt != nullptr;
         QrWork w{V(7).p, (long)n, keep ? out.jpvt : jpvt(), (long)n};
-        w.sync = qsync; w.sync_stride = qrcp_coop_sync_granules(); w.abort_words = qabort; w.info = info();
+        w.sync = qsync; w.sync_stride = qrcp_coop_sync_granules(n); w.abort_words = qabort; w.info = info();
         if (out.tri) *out.tri = keep;
         return launch_to_ldr(A, out.L, out.d, out.R, w, n, C, stream);
     }
@@ -226,6 +226,7 @@ struct Engine {
     void* h_stage = nullptr; size_t h_stage_bytes = 0;           // pinned staging for the random stream
     hipEvent_t stage_free = nullptr;
     double* Upanel = nullptr; double* Wpanel = nullptr;          // [C][KD][n]
+    double* Cpanel = nullptr;                                    // [C][KD][KD]
     int* state = nullptr;                                        // [C][4]
     double* prep = nullptr;                                      // [C][4n]
     double* meas_now = nullptr; double* meas_sum = nullptr;      // [C][3 + n] equal-time observables: last evaluation / bin sums
@@ -264,7 +265,7 @@ struct Engine {
         for (auto& p : ev_pairs) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
         if (stage_free) (void)hipEventDestroy(stage_free);
         void* ptrs[] = {utMeasNow, utMeasSum, utG[0], utG[1], utG[2], utTmp, utErr, utL[0], utL[1], utD[0], utD[1], utR[0], utR[1], utP[0], utP[1], meas_now, meas_sum, GT, slice_sync, prep, stackP, expK, invexpK, fields, expv, invexpv, tabs, tab8, G, Gtmp, bb0, bb1, stackL, stackD, stackR, tmpL, tmpD, tmpR,
-                        logdet, rs_perm, rs_k, rs_u, Upanel, Wpanel, state, acc, err, dstats, r1scratch};
+                        logdet, rs_perm, rs_k, rs_u, Upanel, Wpanel, Cpanel, state, acc, err, dstats, r1scratch};
         for (void* p : ptrs) if (p) (void)hipFree(p);
         if (h_stage) (void)hipHostFree(h_stage);
     }
@@ -289,7 +290,7 @@ struct Engine {
         DQ_TRY(dalloc(&tmpL, C * nn)); DQ_TRY(dalloc(&tmpD, (size_t)C * n)); DQ_TRY(dalloc(&tmpR, C * nn));
         DQ_TRY(dalloc(&logdet, C));
         DQ_TRY(dalloc(&rs_perm, (size_t)C * nt * n)); DQ_TRY(dalloc(&rs_k, (size_t)C * nt * n)); DQ_TRY(dalloc(&rs_u, (size_t)C * nt * n));
-        DQ_TRY(dalloc(&Upanel, (size_t)C * UPDATE_KD * n)); DQ_TRY(dalloc(&Wpanel, (size_t)C * UPDATE_KD * n));
+        DQ_TRY(dalloc(&Upanel, (size_t)C * UPDATE_KD * n)); DQ_TRY(dalloc(&Wpanel, (size_t)C * UPDATE_KD * n)); DQ_TRY(dalloc(&Cpanel, (size_t)C * UPDATE_KD * UPDATE_KD));
         DQ_TRY(dalloc(&state, (size_t)C * 4)); DQ_TRY(dalloc(&prep, (size_t)C * 4 * n)); DQ_TRY(dalloc(&meas_now, (size_t)C * (3 + n))); DQ_TRY(dalloc(&meas_sum, (size_t)C * (3 + n))); DQ_HIP(hipMemsetAsync(meas_sum, 0, sizeof(double) * C * (3 + n), s)); DQ_TRY(dalloc(&slice_sync, (size_t)C * 64)); DQ_HIP(hipMemsetAsync(slice_sync, 0, (size_t)C * 64, s)); DQ_TRY(dalloc(&acc, (size_t)C * nt)); DQ_TRY(dalloc(&err, (size_t)C * n_stack));
         DQ_TRY(dalloc(&dstats, C)); DQ_TRY(dalloc(&r1scratch, (size_t)C * (2 * n + 1)));
         h_stage_bytes = (size_t)C * nt * n * (sizeof(int32_t) + sizeof(uint8_t) + sizeof(double));
@@ -363,7 +364,7 @@ struct Engine {
     }
     UpdateDesc udesc() const {
         UpdateDesc d; d.G = mG(); d.fields = fields; d.f_stride = (long)nt * n; d.expv = expv; d.invexpv = invexpv; d.v_stride = (long)nt * n;
-        d.tabs = tabs; d.perm = rs_perm; d.kprop = rs_k; d.u = rs_u; d.rs_stride = (long)nt * n; d.Upanel = Upanel; d.Wpanel = Wpanel;
+        d.tabs = tabs; d.perm = rs_perm; d.kprop = rs_k; d.u = rs_u; d.rs_stride = (long)nt * n; d.Upanel = Upanel; d.Wpanel = Wpanel; d.Cpanel = Cpanel;
         d.panel_stride = (long)UPDATE_KD * n; d.state = state; d.state_stride = 4; d.prep = prep; d.prep_stride = 4L * n; d.slice_sync = persistent ? slice_sync : nullptr; d.GT = Mat{GT, nn}; d.gt_valid = gt_valid ? 1 : 0; d.info = ctx.info(); d.acc_out = acc; d.acc_stride = nt; d.n = n; d.nt = nt;
         return d;
     }

@@ -254,9 +254,8 @@ int launch_gemm(const GemmDesc& g, int n_chains, hipStream_t s) {
 
 static int launch_gemm_main(const GemmDesc& g, int n_chains, hipStream_t s, bool* ct_done) {
     const int n = g.n;
-    static const bool force_v1 = getenv("DQMC_GEMM_V1") != nullptr;      // A/B switch
     static const bool no_tile64 = getenv("DQMC_GEMM_NO_TILE64") != nullptr;
-    if (!force_v1 && !no_tile64 && n % 64 == 0 && (long)n_chains * (n / 64) * (n / 64) >= 256) {     // enough 64x64 tiles to fill 256 CUs
+    if (!no_tile64 && n % 64 == 0 && (long)n_chains * (n / 64) * (n / 64) >= 256) {     // enough 64x64 tiles to fill 256 CUs
         const int tiles = n / 64;
         dim3 grid(tiles * tiles, n_chains), block(256);
         if (g.transA) hipLaunchKernelGGL((gemm_tile64_kernel<true>), grid, block, 0, s, g, tiles);
@@ -264,7 +263,7 @@ static int launch_gemm_main(const GemmDesc& g, int n_chains, hipStream_t s, bool
         DQ_HIP(hipGetLastError());
         return 0;
     }
-    if (!force_v1 && n <= 640) {
+    if (n <= 640) {
         const int kq = ((n + 3) / 4 + 15) / 16 * 16;                     // k per wave
         if (kq <= 16) launch_splitk<16>(g, n_chains, s);
         else if (kq <= 32) launch_splitk<32>(g, n_chains, s);

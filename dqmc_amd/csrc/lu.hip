@@ -3,18 +3,8 @@
 // (source/stablelinalg.cpp:112,119-123,147,155), restated as LAPACK
 // dgetrf (partial pivoting) + dgetrs.
 //
-//   lu_kernel        one 1024-thread workgroup per chain, right-looking
-//                    elimination streaming the trailing matrix from L2.  Rows
-//                    are NOT swapped: perm[k] records the pivot row of step k
-//                    and the factors stay in the original row order (row
-//                    perm[k] holds row k of U and of the unit-lower L).  Wave w
-//                    owns columns w, w+16, ...; lanes own rows; a wave streams
-//                    its trailing columns in batches (all loads in flight
-//                    before the first use), takes u_c = A[p, c] out of the
-//                    column it just loaded with a lane shuffle, and parks the
-//                    updated column k+1 in LDS, so the pivot search and the
-//                    multipliers of the next step touch no global memory.
-//                    Emits perm and sum log|u_kk|.
+//   (factorisation)  lu_blocked.hip: 32-column panels on chip, MFMA rank-32 trailing update.  Rows are NOT swapped:
+//                    perm[k] records the pivot row of step k and the factors stay in the original row order.
 //   lu_solve_kernel  solve A X = B for n right-hand sides.  Columns of X are
 //                    independent: grid = (n/16 column tiles) x chains, each
 //                    wave keeps 4 columns in registers (lane <-> pivot
@@ -27,89 +17,6 @@
 
 namespace dq {
 
-template <int NR>
-__global__ __launch_bounds__(1024) void lu_kernel(Mat Am, int* perm_p, long perm_stride, double* logabsdet, int accumulate, int* info, int n) {
-    __shared__ double lvec[1024], nextcol[1024];
-    __shared__ double redv[16];
-    __shared__ int redi[16];
-    __shared__ int rowpos[1024];      // -1 = live row, else the step at which it became a pivot row
-    __shared__ int perm[1024];
-    __shared__ int s_bad;
-    constexpr int CB = NR <= 4 ? 8 : (NR <= 9 ? 4 : 2);
-    const int chain = blockIdx.y;
-    double* __restrict__ A = Am.at(chain);
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    if (t < n) { rowpos[t] = -1; nextcol[t] = A[t]; }
-    if (t == 0) s_bad = 0;
-    double logsum = 0.0;      // thread 0 only
-    __syncthreads();
-
-    for (int k = 0; k < n; ++k) {
-        // (a) pivot search over the live rows of column k (LDS image): first max of |a|
-        double best = -1.0; int bi = n;
-        if (t < n && rowpos[t] < 0) { best = fabs(nextcol[t]); bi = t; }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const double ob = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
-            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
-        }
-        if (lane == 0) { redv[wave] = best; redi[wave] = bi; }
-        __syncthreads();
-        best = redv[0]; bi = redi[0];
-#pragma unroll
-        for (int q = 1; q < 16; ++q) { const double ob = redv[q]; const int oi = redi[q]; if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; } }
-        const int p = bi < n ? bi : 0;
-        const double piv = nextcol[p];
-        // (b) multipliers of the live rows
-        if (t < n) {
-            double l = 0.0;
-            if (rowpos[t] < 0 && t != p) { l = nextcol[t] / piv; A[t + (long)n * k] = l; }
-            lvec[t] = l;
-        }
-        __syncthreads();                 // rowpos / nextcol reads done before they change
-        if (t == 0) {
-            rowpos[p] = k; perm[k] = p;
-            if (!(best > 0.0)) s_bad = 1;
-            logsum += log(best);
-        }
-        // (c) trailing update A[r,c] -= l_r * A[p,c] on this wave's columns c > k
-        double lr[NR];
-#pragma unroll
-        for (int q = 0; q < NR; ++q) { const int r = lane + 64 * q; lr[q] = (r < n) ? lvec[r] : 0.0; }
-        const int pq = p >> 6, pl = p & 63;
-        int first = wave; if (first <= k) first += 16 * ((k - first) / 16 + 1);
-        for (int cb = first; cb < n; cb += 16 * CB) {
-            double a[CB][NR];
-#pragma unroll
-            for (int j = 0; j < CB; ++j) {
-                const int c = cb + 16 * j;
-#pragma unroll
-                for (int q = 0; q < NR; ++q) { const int r = lane + 64 * q; a[j][q] = (c < n && r < n) ? A[r + (long)n * c] : 0.0; }
-            }
-#pragma unroll
-            for (int j = 0; j < CB; ++j) {
-                const int c = cb + 16 * j;
-                if (c >= n) continue;
-                double up = 0.0;
-#pragma unroll
-                for (int q = 0; q < NR; ++q) if (q == pq) up = a[j][q];
-                const double uc = __shfl(up, pl, 64);
-#pragma unroll
-                for (int q = 0; q < NR; ++q) {
-                    const int r = lane + 64 * q;
-                    if (lr[q] != 0.0) { a[j][q] -= lr[q] * uc; A[r + (long)n * c] = a[j][q]; }
-                    if (c == k + 1 && r < n) nextcol[r] = a[j][q];
-                }
-            }
-        }
-        __syncthreads();
-    }
-    if (t < n) perm_p[(long)chain * perm_stride + t] = perm[t];
-    if (t == 0) {
-        if (logabsdet) logabsdet[chain] = (accumulate ? logabsdet[chain] : 0.0) + logsum;
-        if (info && s_bad) atomicOr(info, 1);
-    }
-}
 
 // P A = L U with the factors in A's original row order: row perm[k] of LU holds
 // U[k, k:] and L[k, :k].  Lane/register position r of x below is the PIVOT position.
@@ -240,25 +147,14 @@ __global__ __launch_bounds__(256) void lu_solve_kernel(CMat LUm, const int* perm
     }
 }
 
-template <int NR>
-static int launch_lu_nr(Mat A, int* perm, long ps, double* lad, int acc, int* info, int n, int n_chains, hipStream_t s) {
-    hipLaunchKernelGGL((lu_kernel<NR>), dim3(1, n_chains), dim3(1024), 0, s, A, perm, ps, lad, acc, info, n);
-    DQ_HIP(hipGetLastError());
-    return 0;
-}
 int launch_lu_blocked(Mat A, int* perm, long perm_stride, int* rowpos, long rowpos_stride, double* logabsdet, int accumulate_logdet,
                       int* info, int n, int n_chains, hipStream_t s);     // lu_blocked.hip
 
 int launch_lu(Mat A, int* perm, long perm_stride, double* logabsdet, int accumulate_logdet, int* info, int n, int n_chains, hipStream_t s,
               int* rowpos, long rowpos_stride) {
     if (n > 1024) { set_error("LU kernel supports n <= 1024"); return -1; }
-    static const bool force_stream = getenv("DQMC_LU_STREAMING") != nullptr;    // A/B switch for tests and profiling
-    if (rowpos && !force_stream) return launch_lu_blocked(A, perm, perm_stride, rowpos, rowpos_stride, logabsdet, accumulate_logdet, info, n, n_chains, s);
-    if (n <= 64) return launch_lu_nr<1>(A, perm, perm_stride, logabsdet, accumulate_logdet, info, n, n_chains, s);
-    if (n <= 128) return launch_lu_nr<2>(A, perm, perm_stride, logabsdet, accumulate_logdet, info, n, n_chains, s);
-    if (n <= 256) return launch_lu_nr<4>(A, perm, perm_stride, logabsdet, accumulate_logdet, info, n, n_chains, s);
-    if (n <= 576) return launch_lu_nr<9>(A, perm, perm_stride, logabsdet, accumulate_logdet, info, n, n_chains, s);
-    return launch_lu_nr<16>(A, perm, perm_stride, logabsdet, accumulate_logdet, info, n, n_chains, s);
+    if (!rowpos) { set_error("LU: row-position workspace missing"); return -1; }
+    return launch_lu_blocked(A, perm, perm_stride, rowpos, rowpos_stride, logabsdet, accumulate_logdet, info, n, n_chains, s);
 }
 
 template <int NR>

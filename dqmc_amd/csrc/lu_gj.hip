@@ -193,31 +193,20 @@ __device__ __forceinline__ void gj_step_mw(double (&a)[GJ_NB], bool& live, int& 
     rme = fma(fma(-a[J], rme, 1.0), rme, rme);
     const unsigned long long key = live ? ((unsigned long long)__double_as_longlong(fabs(a[J])) | 1ULL) : 0ULL;
     const unsigned hi = (unsigned)(key >> 32), lo = (unsigned)key;
-#if defined(GJ_EXP) && (GJ_EXP & 4)
-    const unsigned m1 = hi, m2 = lo; const unsigned long long winners = 1ULL << (J & 63); const int cl = J & 63;
-#else
     const unsigned m1 = wave_max_u32(hi);
     const unsigned m2 = wave_max_u32(hi == m1 ? lo : 0u);
     const unsigned long long winners = __ballot(hi == m1 && lo == m2 && live);
     const int cl = winners ? (int)__builtin_ctzll(winners) : 0;
-#endif
     if (lane == cl) {                                     // this wave's candidate
-#if !(defined(GJ_EXP) && (GJ_EXP & 8))
 #pragma unroll
         for (int c = C0; c < GJ_NB; c += 2) *reinterpret_cast<double2*>(&slot_row[PAR][wave][c]) = make_double2(a[c], a[c + 1]);
-#endif
         slot_row[PAR][wave][GJ_NB] = rme;
         // key: |a| with its low 9 bits replaced by {non-empty marker, lane}; waves compare bits 8 and up (44 mantissa bits)
         slot_key[PAR][wave] = winners ? ((((unsigned long long)m1 << 32) | m2) & ~0xFFULL) | (unsigned long long)cl | 0x100ULL : 0ULL;
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#if !(defined(GJ_EXP) && (GJ_EXP & 2))
     __builtin_amdgcn_s_barrier();
-#endif
     asm volatile("" ::: "memory");
-#if defined(GJ_EXP) && (GJ_EXP & 16)
-    unsigned long long best = (unsigned long long)(J & 63); int pw = J & 3;
-#else
     // all four keys in ONE LDS round trip (slots of absent waves stay 0 = "no candidate"): reading them under `w < nw` branches
     // made each key its own dependent round trip, ~450 clk per step
     const ulonglong2 k01 = *reinterpret_cast<const ulonglong2*>(&slot_key[PAR][0]);
@@ -226,18 +215,11 @@ __device__ __forceinline__ void gj_step_mw(double (&a)[GJ_NB], bool& live, int& 
     if ((k01.y >> 8) > (best >> 8)) { best = k01.y; pw = 1; }
     if ((k23.x >> 8) > (best >> 8)) { best = k23.x; pw = 2; }
     if ((k23.y >> 8) > (best >> 8)) { best = k23.y; pw = 3; }
-#endif
     const int pl = (int)(best & 0xFFULL);
     double prow[GJ_NB - C0];
-#if defined(GJ_EXP) && (GJ_EXP & 8)
-#pragma unroll
-    for (int c = C0; c < GJ_NB; ++c) prow[c - C0] = 1.0 + 1e-3 * c;
-    const double r = 0.5;
-#else
 #pragma unroll
     for (int c = C0; c < GJ_NB; c += 2) { const double2 v = *reinterpret_cast<const double2*>(&slot_row[PAR][pw][c]); prow[c - C0] = v.x; prow[c + 1 - C0] = v.y; }
     const double r = slot_row[PAR][pw][GJ_NB];
-#endif
     if (lane == J && wave == 0) myperm = pl + 64 * pw;
     if (wave == pw && lane == pl) { live = false; mypos = k0 + J; }
     singular = singular || !(fabs(prow[J - C0]) > 0.0);
@@ -245,10 +227,8 @@ __device__ __forceinline__ void gj_step_mw(double (&a)[GJ_NB], bool& live, int& 
     // scheduled into them
     const double l = live ? a[J] * r : 0.0;
     a[J] = live ? l : a[J];
-#if !(defined(GJ_EXP) && (GJ_EXP & 1))
 #pragma unroll
     for (int c = J + 1; c < GJ_NB; ++c) a[c] = fma(-l, prow[c - C0], a[c]);
-#endif
 }
 template <int J>
 struct GjStepsMW {

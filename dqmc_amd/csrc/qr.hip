@@ -346,25 +346,23 @@ __global__ void assemble_r_kernel(CMat Am, const int* jpvt_p, long jpvt_stride, 
     if (threadIdx.x == 0) d[j] = fabs(A[j + (long)n * col]);
 }
 
-int launch_qrcp_onchip(Mat A, QrWork w, int n, int n_chains, hipStream_t s);   // qr_onchip.hip
 int launch_qrcp_coop(Mat A, QrWork w, int n, int n_chains, hipStream_t s);     // qr_coop.hip
 int launch_qrcp_colown(Mat A, QrWork w, int n, int n_chains, hipStream_t s);   // qr_colown.hip
 
-// NRSEL = 0: on-chip QRCP (n <= 256); otherwise the streaming kernel with NRSEL rows per lane
+// NRSEL = 0: on-chip QRCP (n <= 256: the single-CU column-owner kernel); -1: P cooperating workgroups (n > 256);
+// otherwise the single-workgroup streaming kernel with NRSEL rows per lane
 template <int NRSEL>
 static int launch_to_ldr_nr(Mat A, Mat L, Vec d, Mat R, QrWork w, int n, int n_chains, hipStream_t s) {
-    constexpr int NR = NRSEL == 0 ? 4 : NRSEL;
-    if (NRSEL == 0) {
-        // 128 < n <= 256: eight cooperating workgroups, the matrix entirely in registers; n <= 128: one workgroup
-        // (opt-in: measured 1.26 ms vs 1.22 ms for the single-workgroup kernel at n = 256 -- a cross-CU round trip costs
-        // ~1.5 us on this chip and a step needs three of them -- so the default stays the kernel with no cross-workgroup protocol)
-        static const bool use_coop = getenv("DQMC_QR_COOP") != nullptr;
-        static const bool use_blockcyclic = getenv("DQMC_QR_BLOCKCYCLIC") != nullptr;     // A/B switch: the 2-D block-cyclic single-workgroup kernel
-        if (n > 128 && w.sync && use_coop && 8 * n_chains <= 2048) DQ_TRY_RC(launch_qrcp_coop(A, w, n, n_chains, s));
-        else if (use_blockcyclic) DQ_TRY_RC(launch_qrcp_onchip(A, w, n, n_chains, s));
-        else DQ_TRY_RC(launch_qrcp_colown(A, w, n, n_chains, s));
+    constexpr int NR = NRSEL <= 0 ? 4 : NRSEL;
+    if (NRSEL <= 0) {
+        if (NRSEL == 0) DQ_TRY_RC(launch_qrcp_colown(A, w, n, n_chains, s));
+        else DQ_TRY_RC(launch_qrcp_coop(A, w, n, n_chains, s));
         if (formq_blocked_ok(n)) launch_formq_blocked(CMat(A), w, L, n, n_chains, s);
-        else hipLaunchKernelGGL((formq_kernel<4 * NR>), dim3((n + 15) / 16, n_chains), dim3(256), 0, s, CMat(A), (const double*)w.tau, w.tau_stride,
+        else if (n <= 256) hipLaunchKernelGGL((formq_kernel<16>), dim3((n + 15) / 16, n_chains), dim3(256), 0, s, CMat(A), (const double*)w.tau, w.tau_stride,
+                                              (const int*)w.jpvt, w.jpvt_stride, L, n);
+        else if (n <= 576) hipLaunchKernelGGL((formq_kernel<36>), dim3((n + 15) / 16, n_chains), dim3(256), 0, s, CMat(A), (const double*)w.tau, w.tau_stride,
+                                              (const int*)w.jpvt, w.jpvt_stride, L, n);
+        else hipLaunchKernelGGL((formq_kernel<64>), dim3((n + 15) / 16, n_chains), dim3(256), 0, s, CMat(A), (const double*)w.tau, w.tau_stride,
                                 (const int*)w.jpvt, w.jpvt_stride, L, n);
         hipLaunchKernelGGL(assemble_r_kernel, dim3(n, n_chains), dim3(128), 0, s, CMat(A), (const int*)w.jpvt, w.jpvt_stride, d, R, n);
         DQ_HIP(hipGetLastError());
@@ -392,6 +390,10 @@ int launch_to_ldr(Mat A, Mat L, Vec d, Mat R, QrWork w, int n, int n_chains, hip
     if (n > 1024) { set_error("to_LDR kernel supports n <= 1024"); return -1; }
     static const bool force_stream = getenv("DQMC_QR_STREAMING") != nullptr;    // A/B switch for tests and profiling
     if (n <= 256 && !force_stream) return launch_to_ldr_nr<0>(A, L, d, R, w, n, n_chains, s);
+    // n > 256: the matrix does not fit one CU; ceil(n/32) cooperating workgroups while they fit the CU budget (co-residency), the
+    // single-workgroup streaming kernel otherwise (many chains per launch: every CU is busy with its own chain anyway)
+    if (n > 256 && !force_stream && w.sync && w.sync_stride >= qrcp_coop_sync_granules(n) && qrcp_coop_workgroups(n, n_chains) <= 200)
+        return launch_to_ldr_nr<-1>(A, L, d, R, w, n, n_chains, s);
     if (n <= 64) return launch_to_ldr_nr<1>(A, L, d, R, w, n, n_chains, s);
     if (n <= 128) return launch_to_ldr_nr<2>(A, L, d, R, w, n, n_chains, s);
     if (n <= 256) return launch_to_ldr_nr<4>(A, L, d, R, w, n, n_chains, s);

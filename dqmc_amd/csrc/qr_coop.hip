@@ -1,32 +1,28 @@
-// qr_coop.hip -- column-pivoted Householder QR for 128 < n <= 256 spread over
-// QC_P = 8 cooperating workgroups per chain (to_LDR, source/stablelinalg.cpp:35-55; same
-// LAPACK dlaqp2 semantics and output format as qr.hip / qr_onchip.hip: reflectors
-// and R0 left in place in A, jpvt / tau out).
+// qr_coop.hip -- column-pivoted Householder QR for 256 < n <= 1024 spread over P = ceil(n / 32) cooperating
+// workgroups per chain (to_LDR, source/stablelinalg.cpp:35-55; LAPACK dlaqp2 semantics and the output format of
+// qr.hip / qr_colown.hip: reflectors and R0 left in place in A without column swaps, jpvt / tau out).
 //
-// Why: one CU cannot hold a 256 x 256 fp64 matrix next to its working registers
-// (qr_onchip.hip: 2 of 8 columns per thread live in LDS, whose write bandwidth
-// then paces the update: 1.2 ms per factorisation), and a single CU's fp64 rate
-// sets a 0.1 ms floor anyway.  Here every workgroup (256 threads, one wave per
-// SIMD) owns 32 columns entirely in registers (32 doubles per thread, no LDS data,
-// no spills) and the 256 serial steps cost one all-to-all exchange each:
+// Why: beyond n = 256 the matrix no longer fits one CU (n = 576: 2.65 MB against 512 KB of registers + 160 KB of LDS), and
+// the single-workgroup streaming kernel of qr.hip re-reads it from L2 every step: 23.7 ms per factorisation at n = 576,
+// 59 % of a cfg-5 sweep (profiles/r02_bench_cfg5_kernel_stats_v1.csv).  Here every workgroup (256 threads, one wave per
+// SIMD) owns 32 columns entirely in registers (2 columns x ceil(n/16) row slots per thread, no LDS data, no spills) and
+// each of the n serial steps costs one all-to-all exchange:
 //
-//   step i:  every workgroup builds the Householder reflector of ITS best live
-//            column (largest partial norm) speculatively and publishes
-//            {key, tau, beta, v[0:256]} as data-tagged 8-byte granules
+//   step i:  every workgroup builds the Householder reflector of ITS best live column (largest partial norm)
+//            speculatively and publishes {norm, column, tau, beta, v[0:n]} as data-tagged 8-byte granules
 //            (tag = step + 1, relaxed agent-scope atomic stores = sc1, write-through);
-//            every workgroup sweeps all 8 records until the tags match, takes the
-//            record with the largest key -- all workgroups reach the same decision
-//            without a barrier or a flag -- and applies that reflector to its live
-//            columns.  The winner also writes the reflector / tau / jpvt to HBM.
+//            every workgroup sweeps the P headers until the tags match, takes the record with the largest norm (lowest
+//            column on ties: dgeqp3's idamax rule, exactly -- norms are compared as full doubles) -- all workgroups
+//            reach the same decision without a barrier or a flag --, reads that record's payload and applies the reflector
+//            to its live columns.  The winner also writes the reflector / tau / jpvt to HBM.
 //
-// This is recipe R2 of cdna_hip_programming.md, Guideline 16 (the data is the flag;
-// every shared word is an 8-byte agent-scope access, tags never 0, buffers zeroed by a
-// memset node before every launch, spins bounded with an abort word).  Records are
-// double-buffered by step parity: a workgroup can publish step i+1 only after it has
-// read every step-i record, so a reader of step i never sees its slot overwritten.
-// Placement-independent: nothing relies on which XCD / CU a workgroup runs on; the 8
-// workgroups of a chain must be co-resident (8 x chains <= resident slots; checked
-// by the launcher against the CU count).
+// This is recipe R2 of cdna_hip_programming.md, Guideline 16 (the data is the flag; every shared word is an 8-byte
+// agent-scope access, tags never 0, buffers zeroed by a memset node before every launch, spins bounded with an abort
+// word).  Records are double-buffered by step parity: a workgroup can publish step i+1 only after it has read every
+// step-i header and the winner's payload, so a reader of step i never sees its slot overwritten.  Placement-independent:
+// nothing relies on which XCD / CU a workgroup runs on; the P workgroups of a chain must be co-resident (the launcher
+// takes this path only while P x chains fits the CU budget, and a spin that expires reports DQMC_ENUMERIC, never a hang).
+// At n <= 256 the single-CU column-owner kernel (qr_colown.hip) is faster: a cross-CU round trip costs ~1.5 us here.
 #include "common.h"
 #include "wave.h"
 
@@ -34,17 +30,16 @@ namespace dq {
 
 namespace {
 
-constexpr int QC_P = 8;                     // workgroups per chain
 constexpr int QC_COLS = 32;                 // columns per workgroup
 constexpr int QC_T = 256;                   // threads per workgroup
-constexpr int QC_REC = 8 + 2 * 256;         // granules per record: header (key, tau, beta, spare) + v[256]
+constexpr int QC_HDR = 4;                   // header slots of a record: norm, column, tau, beta
 constexpr unsigned QC_SPIN_LIMIT = 1u << 18;     // ~0.2 s of polling; one time-out raises the abort word and ends every later spin at once
 
 using u64 = unsigned long long;
 
-__device__ __forceinline__ u64 qc_key(double nrm, int c) {
-    return (1ULL << 63) | ((u64)__double_as_longlong(nrm) & ~0xFFULL) | (u64)(255 - c);
-}
+__host__ __device__ inline int qc_workgroups(int n) { return (n + QC_COLS - 1) / QC_COLS; }
+__host__ __device__ inline long qc_rec_granules(int n) { return 2L * (QC_HDR + n); }      // one fp64 slot = two tagged granules
+
 __device__ __forceinline__ void put_f64(u64* rec, int slot, double x, unsigned tag) {
     const u64 b = (u64)__double_as_longlong(x);
     __hip_atomic_store(rec + 2 * slot, ((u64)tag << 32) | (b & 0xffffffffULL), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -57,18 +52,30 @@ __device__ __forceinline__ bool get_f64(const u64* rec, int slot, unsigned tag, 
     x = __longlong_as_double((long long)(((hi & 0xffffffffULL) << 32) | (lo & 0xffffffffULL)));
     return (unsigned)(lo >> 32) == tag && (unsigned)(hi >> 32) == tag;
 }
+// idamax over the wave: the largest norm among the valid lanes, the lowest column among the lanes that hold it.
+// Norms are non-negative, so their bit patterns order like the numbers; bit 63 marks "valid".  Returns false when no lane is valid.
+__device__ __forceinline__ bool wave_argmax_norm(double nrm, int col, bool valid, int& best_col) {
+    const u64 bits = valid ? ((1ULL << 63) | (u64)__double_as_longlong(nrm)) : 0ULL;
+    const u64 top = wave_max_u64(bits);
+    const unsigned c = (valid && bits == top) ? ~(unsigned)col : 0u;
+    best_col = (int)~wave_max_u32(c);
+    return top != 0ULL;
+}
 
 }  // namespace
 
-// grid = (QC_P, chains); sync: [chains][2][QC_P][QC_REC] granules (zeroed before launch); abort_word: 1 int per chain
+// grid = (P, chains); sync: [chains][2][P][qc_rec_granules(n)] granules (zeroed before launch); abort_word: 1 int per chain
+// NB: row slots per thread (rows 16 j + rg), NB * 16 >= n
+template <int NB>
 __global__ __launch_bounds__(QC_T) void qrcp_coop_kernel(Mat Am, QrWork w, int n, u64* sync_p, long sync_stride, int* abort_p, int* info) {
-    __shared__ double xbuf[256];            // image of my candidate column
-    __shared__ double vbuf[256];            // the winning Householder vector of this step
+    __shared__ double xbuf[16 * NB];        // image of my candidate column
+    __shared__ double vbuf[16 * NB];        // the winning Householder vector of this step
     __shared__ double rowi[QC_COLS];        // row i of my columns (norm down-date)
     __shared__ double tails[QC_COLS];       // recomputed tail norms^2 (rare path)
     __shared__ double scal[4];              // tau, beta, scale of my candidate
     __shared__ int pposl[QC_COLS];          // pivot position of a pivoted column of mine
-    const int chain = blockIdx.y, wg = blockIdx.x;
+    const int chain = blockIdx.y, wg = blockIdx.x, P = gridDim.x;
+    const long REC = qc_rec_granules(n);
     double* __restrict__ A = Am.at(chain);
     double* tau = w.tau + (long)chain * w.tau_stride;
     int* jpvt = w.jpvt + (long)chain * w.jpvt_stride;
@@ -80,17 +87,17 @@ __global__ __launch_bounds__(QC_T) void qrcp_coop_kernel(Mat Am, QrWork w, int n
     const int gc0 = QC_COLS * wg + lc0;                // global column of local column lc0
     const double tol3z = 1.0536712127723509e-08;       // sqrt(2^-53)
 
-    double a[2][16];
+    double a[2][NB];
     unsigned wlive;                                    // bit q: local column q is live (same in every thread)
     { const int cnt = n - QC_COLS * wg; wlive = cnt >= 32 ? 0xFFFFFFFFu : (cnt > 0 ? ((1u << cnt) - 1u) : 0u); }
-    if (t < QC_COLS) pposl[t] = 256;
+    if (t < QC_COLS) pposl[t] = 1 << 30;
 
     // ---- load my columns, initial norms (every lane q < 32 of every wave keeps the norm of local column q) ----
     double nrm1 = 0.0, nrm2 = 0.0;                      // vn1 / vn2 of local column (lane & 31), valid in lanes 0..31
     {
         double n0 = 0.0, n1 = 0.0;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
+        for (int j = 0; j < NB; ++j) {
             const int r = 16 * j + rg;
             a[0][j] = (r < n && gc0 < n) ? A[r + (long)n * gc0] : 0.0;
             a[1][j] = (r < n && gc0 + 1 < n) ? A[r + (long)n * (gc0 + 1)] : 0.0;
@@ -104,13 +111,14 @@ __global__ __launch_bounds__(QC_T) void qrcp_coop_kernel(Mat Am, QrWork w, int n
     }
 
     for (int i = 0; i < n; ++i) {
-        const int jb = i >> 4, nj = 16 - jb;            // slot j <-> row block jb + j
+        const int jb = i >> 4, nj = NB - jb;            // slot j <-> row block jb + j
         const unsigned tag = (unsigned)i + 1u;
-        u64* myrec = sync + ((long)(i & 1) * QC_P + wg) * QC_REC;
+        u64* myrec = sync + ((long)(i & 1) * P + wg) * REC;
         // ---- [1] my best live column (identical in all four waves: same inputs, no exchange) ----
-        u64 mykey = (lane < 32 && ((wlive >> lane) & 1u)) ? qc_key(nrm1, QC_COLS * wg + lane) : 0ULL;
-        mykey = wave_max_u64(mykey);
-        const int cstar = mykey ? (255 - (int)(mykey & 0xFFULL)) - QC_COLS * wg : 0;   // local column 0..31
+        int cbest = 0;
+        const bool have = wave_argmax_norm(nrm1, QC_COLS * wg + lane, lane < 32 && ((wlive >> lane) & 1u), cbest);
+        const int cstar = have ? cbest - QC_COLS * wg : 0;                              // local column 0..31
+        const double mynorm = readlane_f64(nrm1, cstar);
         // ---- [2] its Householder reflector, built speculatively ----
         if (wave == (cstar >> 3)) {
             const bool mine = cl == ((cstar & 7) >> 1);
@@ -119,7 +127,7 @@ __global__ __launch_bounds__(QC_T) void qrcp_coop_kernel(Mat Am, QrWork w, int n
             // array access, which sends the whole register image of the matrix to scratch
 #define QC_PUBLISH(KC)                                                  \
             {                                                           \
-                _Pragma("unroll") for (int j = 0; j < 16; ++j) {        \
+                _Pragma("unroll") for (int j = 0; j < NB; ++j) {        \
                     if (j < nj) {                                       \
                         const int r = 16 * (jb + j) + rg;               \
                         const double x = a[KC][j];                      \
@@ -143,55 +151,54 @@ __global__ __launch_bounds__(QC_T) void qrcp_coop_kernel(Mat Am, QrWork w, int n
             }
         }
         __syncthreads();
-        // ---- [3] publish {key, tau, beta, v} as tagged granules ----
-        double vmine = 0.0;
-        if (mykey) {
-            if (t == i) vmine = 1.0; else if (t > i) vmine = xbuf[t] * scal[2];
+        // ---- [3] publish {norm, column, tau, beta, v} as tagged granules ----
+        for (int r = t; r < n; r += QC_T) {
+            double vmine = 0.0;
+            if (have) { if (r == i) vmine = 1.0; else if (r > i) vmine = xbuf[r] * scal[2]; }
+            put_f64(myrec, QC_HDR + r, vmine, tag);
         }
-        put_f64(myrec, 4 + t, vmine, tag);
         if (t == 0) {
-            const u64 k = mykey;
-            __hip_atomic_store(myrec + 0, ((u64)tag << 32) | (k & 0xffffffffULL), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(myrec + 1, ((u64)tag << 32) | (k >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            put_f64(myrec, 1, mykey ? scal[0] : 0.0, tag);
-            put_f64(myrec, 2, mykey ? scal[1] : 0.0, tag);
+            put_f64(myrec, 0, have ? mynorm : -1.0, tag);
+            put_f64(myrec, 1, have ? (double)cbest : -1.0, tag);
+            put_f64(myrec, 2, have ? scal[0] : 0.0, tag);
+            put_f64(myrec, 3, have ? scal[1] : 0.0, tag);
         }
-        // ---- [4] sweep the records: keys first (lanes 0..7 of every wave, one record each), then the winner's payload.
-        //          (Reading all eight payloads speculatively in the same pass was tried: 64 sc1 loads per thread per poll
-        //          cost more than the dependent round trip they save: 1.83 ms vs 1.26 ms per factorisation.) ----
-        const u64* recs = sync + (long)(i & 1) * QC_P * QC_REC;
-        u64 best = 0ULL;
+        // ---- [4] sweep the headers (lane q < P of every wave reads record q), then the winner's payload ----
+        const u64* recs = sync + (long)(i & 1) * P * REC;
+        int p = 0;                                            // global pivot column
         {
             unsigned spins = 0;
             for (;;) {
-                u64 k = 0ULL; bool ok = true;
-                if (lane < QC_P) {
-                    const u64 lo = __hip_atomic_load(recs + (long)lane * QC_REC + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const u64 hi = __hip_atomic_load(recs + (long)lane * QC_REC + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    ok = (unsigned)(lo >> 32) == tag && (unsigned)(hi >> 32) == tag;
-                    k = ((hi & 0xffffffffULL) << 32) | (lo & 0xffffffffULL);
-                }
-                if (__all(ok)) { best = wave_max_u64(k); break; }
+                double hn = -1.0, hc = -1.0; bool ok = true;
+                if (lane < P) { const bool o1 = get_f64(recs + (long)lane * REC, 0, tag, hn), o2 = get_f64(recs + (long)lane * REC, 1, tag, hc); ok = o1 && o2; }
+                const bool all_ok = __all(ok);
                 // bounded spin: give up, raise the chain's abort word (every later spin of every workgroup then exits at
                 // once) and carry on with whatever was read -- the barrier structure stays intact, the kernel ends in
                 // bounded time, the host sees info bit 1 and reports the factorisation as failed
-                if (++spins > QC_SPIN_LIMIT || __hip_atomic_load(abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                bool bail = false;
+                if (!all_ok && (++spins > QC_SPIN_LIMIT || __hip_atomic_load(abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
                     __hip_atomic_store(abort_w, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (info && lane == 0) atomicOr(info, 2);
-                    best = wave_max_u64(k); break;
+                    bail = true;
+                }
+                if (all_ok || bail) {
+                    int pc = 0;
+                    const bool any = wave_argmax_norm(hn, (int)hc, lane < P && ok && hn >= 0.0, pc);
+                    p = any ? pc : 0;
+                    break;
                 }
                 __builtin_amdgcn_s_sleep(1);
             }
         }
-        const int p = 255 - (int)(best & 0xFFULL);           // global pivot column
-        const int wwin = p >> 5;                             // its workgroup
-        const u64* wrec = recs + (long)wwin * QC_REC;
-        double tau_i = 0.0, beta = 0.0, vr = 0.0;
+        const int wwin = p / QC_COLS;                        // its workgroup
+        const u64* wrec = recs + (long)wwin * REC;
+        double tau_i = 0.0, beta = 0.0;
         {
             unsigned spins = 0;
             for (;;) {
-                const bool ok_v = get_f64(wrec, 4 + t, tag, vr), ok_t = get_f64(wrec, 1, tag, tau_i), ok_b = get_f64(wrec, 2, tag, beta);
-                const bool ok = ok_v && ok_t && ok_b;
+                bool ok = get_f64(wrec, 2, tag, tau_i);
+                ok = get_f64(wrec, 3, tag, beta) && ok;
+                for (int r = t; r < n; r += QC_T) { double vr; ok = get_f64(wrec, QC_HDR + r, tag, vr) && ok; vbuf[r] = vr; }
                 if (__all(ok)) break;
                 if (++spins > QC_SPIN_LIMIT || __hip_atomic_load(abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
                     __hip_atomic_store(abort_w, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -201,10 +208,9 @@ __global__ __launch_bounds__(QC_T) void qrcp_coop_kernel(Mat Am, QrWork w, int n
                 __builtin_amdgcn_s_sleep(1);
             }
         }
-        vbuf[t] = vr;
         // ---- [5] the winner records the reflector, tau, jpvt ----
         if (wwin == wg) {
-            if (t < n) { if (t == i) A[t + (long)n * p] = beta; else if (t > i) A[t + (long)n * p] = vr; }
+            for (int r = t; r < n; r += QC_T) { if (r == i) A[r + (long)n * p] = beta; else if (r > i) A[r + (long)n * p] = vbuf[r]; }
             if (t == 0) { tau[i] = tau_i; jpvt[i] = p; pposl[p & 31] = i; }
             wlive &= ~(1u << (p & 31));
         }
@@ -214,14 +220,14 @@ __global__ __launch_bounds__(QC_T) void qrcp_coop_kernel(Mat Am, QrWork w, int n
         {
             double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
+            for (int j = 0; j < NB; ++j) {
                 if (j < nj) { const double vj = vbuf[16 * (jb + j) + rg]; s0 += a[0][j] * vj; s1 += a[1][j] * vj; }
             }
             s0 = row16_sum(s0) * tau_i; s1 = row16_sum(s1) * tau_i;
             if (!live0) s0 = 0.0;
             if (!live1) s1 = 0.0;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
+            for (int j = 0; j < NB; ++j) {
                 if (j < nj) { const double vj = vbuf[16 * (jb + j) + rg]; a[0][j] -= s0 * vj; a[1][j] -= s1 * vj; }
             }
         }
@@ -239,7 +245,7 @@ __global__ __launch_bounds__(QC_T) void qrcp_coop_kernel(Mat Am, QrWork w, int n
         if (needmask) {                                                               // rare: recompute the flagged norms
             double t0 = 0.0, t1 = 0.0;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
+            for (int j = 0; j < NB; ++j) {
                 if (j < nj && 16 * (jb + j) + rg > i) { t0 += a[0][j] * a[0][j]; t1 += a[1][j] * a[1][j]; }
             }
             t0 = row16_sum(t0); t1 = row16_sum(t1);
@@ -257,22 +263,27 @@ __global__ __launch_bounds__(QC_T) void qrcp_coop_kernel(Mat Am, QrWork w, int n
             }
             if ((i & 15) == 15) {
 #pragma unroll
-                for (int j = 0; j < 15; ++j) { a[0][j] = a[0][j + 1]; a[1][j] = a[1][j + 1]; }
+                for (int j = 0; j < NB - 1; ++j) { a[0][j] = a[0][j + 1]; a[1][j] = a[1][j + 1]; }
             }
         }
     }
 }
 
+long qrcp_coop_sync_granules(int n) { return 2L * qc_workgroups(n) * qc_rec_granules(n); }
+// how many CUs the cooperating workgroups of one launch occupy (one workgroup per CU at these register counts)
+int qrcp_coop_workgroups(int n, int n_chains) { return qc_workgroups(n) * n_chains; }
+
 int launch_qrcp_coop(Mat A, QrWork w, int n, int n_chains, hipStream_t s) {
-    if (n > 256) { set_error("cooperative QRCP supports n <= 256"); return -1; }
-    if (!w.sync || w.sync_stride < 2L * QC_P * QC_REC || !w.abort_words) { set_error("cooperative QRCP needs its sync workspace"); return -1; }
+    if (n > 1024) { set_error("cooperative QRCP supports n <= 1024"); return -1; }
+    if (!w.sync || w.sync_stride < qrcp_coop_sync_granules(n) || !w.abort_words) { set_error("cooperative QRCP needs its sync workspace"); return -1; }
     DQ_HIP(hipMemsetAsync(w.sync, 0, sizeof(unsigned long long) * w.sync_stride * n_chains, s));
     DQ_HIP(hipMemsetAsync(w.abort_words, 0, sizeof(int) * n_chains, s));
-    hipLaunchKernelGGL(qrcp_coop_kernel, dim3(QC_P, n_chains), dim3(QC_T), 0, s, A, w, n, (unsigned long long*)w.sync, w.sync_stride, w.abort_words, w.info);
+    const dim3 grid(qc_workgroups(n), n_chains), block(QC_T);
+#define QC_LAUNCH(NB) hipLaunchKernelGGL((qrcp_coop_kernel<NB>), grid, block, 0, s, A, w, n, (unsigned long long*)w.sync, w.sync_stride, w.abort_words, w.info)
+    if (n <= 256) QC_LAUNCH(16); else if (n <= 384) QC_LAUNCH(24); else if (n <= 576) QC_LAUNCH(36); else if (n <= 768) QC_LAUNCH(48); else QC_LAUNCH(64);
+#undef QC_LAUNCH
     DQ_HIP(hipGetLastError());
     return 0;
 }
-
-long qrcp_coop_sync_granules() { return 2L * QC_P * QC_REC; }
 
 }  // namespace dq

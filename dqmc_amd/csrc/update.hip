@@ -840,6 +840,11 @@ int launch_update_slice(const UpdateDesc& d, int l, int acc_slot, int n_chains, 
     }
     static const bool multi_kernel = getenv("DQMC_SLICE_MULTIKERNEL") != nullptr;      // A/B switch
     // persistent single-launch path: needs every workgroup of a chain resident at once, one per CU (the walk's LDS)
+    // sub-matrix updates (update_sm.hip): the same Markov chain from k x k algebra per proposal instead of 2 n k flops per accepted flip.
+    // Opt-in: measured 211 us per cfg-3 slice against 138 us for the delayed-update walk below -- the k x k algebra is a dependent chain
+    // on one wave per SIMD (860 clk per two-proposal pass, 1780 clk per accepted flip), see DESIGN.md
+    static const bool submatrix_walk = getenv("DQMC_WALK_SUBMATRIX") != nullptr;
+    if (!multi_kernel && regs && d.slice_sync && d.Cpanel && submatrix_walk) return launch_update_slice_sm(d, l, acc_slot, n_chains, s);
     if (!multi_kernel && regs && d.slice_sync) {                    // slice_sync is only handed out with a CU reservation (slice_reserve)
         hipLaunchKernelGGL(slice_kernel, dim3(1 + tiles * tiles, n_chains), dim3(256), lds, s, d, reinterpret_cast<SliceSync*>(d.slice_sync), l, acc_slot, kd,
                            tiles, d.info);

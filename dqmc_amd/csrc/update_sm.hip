@@ -1,0 +1,437 @@
+// update_sm.hip -- update::local_update (source/update.cpp:5-32) for one time slice with SUB-MATRIX updates: the
+// second of the two speed-ups the reference's README lists as future work ("delayed / sub-matrix updates",
+// README.md:41).  Persistent single-launch kernel for n <= 256 and few chains; the
+// delayed-update kernels of update.hip remain the path for batched engines and n > 256.
+//
+// Within a window of up to KD = 32 accepted flips at sites S = (s_1 .. s_k) the Green's function is never touched.
+// Every accepted flip is a rank-1 change (AttractiveHubbard::update_greens_local, source/model.cpp:124-138) whose
+// column factor lies in span G0[:, S] and whose row factor lies in span (G0[S, :] - E_S^T), so
+//
+//     G_k = G0 + A C_k B^T,      A = G0[:, S]  (n x k),   B^T = G0[S, :] - E_S^T  (k x n),   C_k  k x k.
+//
+// The acceptance ratio of a proposal at site j (each site is visited once per slice, so j is not in S) needs
+//     G_k[j, j] = G0[j, j] + alpha^T C_k beta,      alpha = A[j, :] = G0[j, S],   beta = B[j, :] = G0[S, j],
+// i.e. k^2 flops on the k x k matrix instead of the 2 n k flops per accepted flip of the delayed update, and an
+// accepted flip extends C by one row and column:
+//     u~ = [C beta; 1],  w~ = [C^T alpha; 1],  C <- [[C, 0], [0, 0]] + pref u~ w~^T,   pref = delta / (1 + (1 - G_jj) delta).
+// When the window closes,  G += (A C) B^T  is applied by the flush workgroups on the matrix cores.  The Markov chain
+// is the reference's; only the rounding order differs (1e-14 against the sequential rank-1 form, tests/test_oracle.py).
+//
+// Walk workgroup (256 threads, one wave per SIMD, thread t <-> site t):
+//   * LDS holds A^T and B^T of the window: cols[m][t] = G0[t, s_m], rows[m][t] = G0[s_m, t] - [t == s_m], written by
+//     all threads when flip m is accepted from the column / row elements every thread prefetches for every proposal
+//     (as in the delayed-update walk; G0 does not change inside a window, so the prefetch is exact);
+//   * every wave keeps its own copy of C and C^T in registers (lane m of each 32-lane half holds row m) and evaluates
+//     the SAME two proposals per pass (half 0: proposal pos, half 1: proposal pos + 1): y = C beta with the beta_n
+//     broadcast by the DPP network (v_fmac_f64_dpp row_newbcast), alpha^T y by a DPP reduction over the half.  All
+//     waves take identical decisions, so the only synchronisation is one LDS barrier per accepted flip (the cols / rows
+//     slot of the flip must be complete before the next pass reads it);
+//   * nothing is stored to memory inside a window; at its end A^T, B^T (from LDS) and C go to the panel buffers.
+// Flush workgroups (one 32 x 32 tile of G and of its transposed copy GT each, one 16 x 16 sub-tile per wave):
+//   D1 = C^T A^T (matrix cores), whose accumulator registers are directly the operands of the two final chains
+//   G_tile += D1^T B^T and GT_tile += B D1 (an MFMA D tile is the next product's A / B operand without a shuffle).
+// Hand-off protocol: the one of slice_kernel in update.hip (tagged window word, arrival counter, exit ticket).
+#include "common.h"
+#include <cstdlib>
+#include "wave.h"
+
+namespace dq {
+
+namespace {
+
+using d4 = __attribute__((ext_vector_type(4))) double;
+
+__constant__ int c_proposal_sm[4][3] = {{1, 2, 3}, {0, 2, 3}, {0, 1, 3}, {0, 1, 2}};   // include/field.h:45-48
+
+constexpr int SM_KD = UPDATE_KD;               // window: 2 x 16 broadcast slots per 16-lane row
+constexpr int SM_LS = 257;                     // LDS row stride of cols / rows (doubles): rows m = 0..15 land in distinct banks
+constexpr unsigned SM_SPIN_LIMIT = 1u << 20;
+
+__device__ __forceinline__ double ld_coh(const double* p) {
+    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void st_coh(double* p, double x) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void lds_barrier() {              // orders LDS traffic only (no vmcnt(0): the prefetch stays in flight)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ double shfl_f64(double x, int src_lane) {
+    const long long b = __double_as_longlong(x);
+    const int lo = __builtin_amdgcn_ds_bpermute(src_lane << 2, (int)(b & 0xffffffffLL));
+    const int hi = __builtin_amdgcn_ds_bpermute(src_lane << 2, (int)(b >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+struct SmShared {
+    double* cols; double* rows;                 // [KD][SM_LS]
+    double* diag0; double* dlt; double* rbv; double* ur; double* tl;
+    int* site; signed char* newf; int* acc_site;
+};
+__host__ __device__ inline size_t sm_lds_bytes(int n) {
+    return (size_t)2 * SM_KD * SM_LS * 8 + (size_t)n * 32 + 256 + (size_t)n * 4 + (((size_t)n + 7) & ~(size_t)7) + SM_KD * 4 + 64;
+}
+__device__ __forceinline__ void sm_shared_init(SmShared& sh, unsigned char* smem, int n) {
+    sh.cols = reinterpret_cast<double*>(smem);
+    sh.rows = sh.cols + SM_KD * SM_LS;
+    sh.diag0 = sh.rows + SM_KD * SM_LS;
+    sh.dlt = sh.diag0 + n; sh.rbv = sh.dlt + n; sh.ur = sh.rbv + n; sh.tl = sh.ur + n;
+    sh.site = reinterpret_cast<int*>(sh.tl + 32);
+    sh.newf = reinterpret_cast<signed char*>(sh.site + n);
+    sh.acc_site = reinterpret_cast<int*>(sh.newf + ((n + 7) & ~7));
+}
+
+// G[t, site] (PC##q) and G[site, t] (PR##q, from the transposed copy) of the 8 proposals of group gg, thread t.  The sixteen values
+// of a group are SCALARS named by token pasting, not arrays: the accepted proposal's pair is selected by a switch, and with arrays
+// the optimiser folds that switch into one dynamically indexed load, which pins all three register sets in scratch.
+#define SM_DECL8(P) double P##0 = 0.0, P##1 = 0.0, P##2 = 0.0, P##3 = 0.0, P##4 = 0.0, P##5 = 0.0, P##6 = 0.0, P##7 = 0.0
+#define SM_LOAD1(PC, PR, gg, q)                                                                                     \
+    {                                                                                                               \
+        const int i_ = sh.site[min((gg) * 8 + q, n - 1)];             /* clamped: loads stay unconditional */       \
+        const unsigned off8_ = (unsigned)(tt + n * i_) * 8u;                                                        \
+        PC##q = ld_coh(reinterpret_cast<const double*>(reinterpret_cast<const char*>(G) + off8_));                  \
+        PR##q = ld_coh(reinterpret_cast<const double*>(reinterpret_cast<const char*>(GT) + off8_));                 \
+    }
+#define SM_LOAD8(PC, PR, gg)                                                                                        \
+    SM_LOAD1(PC, PR, gg, 0) SM_LOAD1(PC, PR, gg, 1) SM_LOAD1(PC, PR, gg, 2) SM_LOAD1(PC, PR, gg, 3)                 \
+    SM_LOAD1(PC, PR, gg, 4) SM_LOAD1(PC, PR, gg, 5) SM_LOAD1(PC, PR, gg, 6) SM_LOAD1(PC, PR, gg, 7)
+#define SM_PICK8(PC, PR)                                                                                            \
+    switch (first) {                                                                                                \
+        case 0: gc = PC##0; gr = PR##0; break; case 1: gc = PC##1; gr = PR##1; break;                               \
+        case 2: gc = PC##2; gr = PR##2; break; case 3: gc = PC##3; gr = PR##3; break;                               \
+        case 4: gc = PC##4; gr = PR##4; break; case 5: gc = PC##5; gr = PR##5; break;                               \
+        case 6: gc = PC##6; gr = PR##6; break; default: gc = PC##7; gr = PR##7; break;                              \
+    }
+
+// acc_a += bcast(pv, lane R0) * M[MB] + bcast(pv, R2) * M[MB + 2];  acc_b += bcast(pv, R1) * M[MB + 1] + bcast(pv, R3) * M[MB + 3]
+// (pv: lane r of every 16-lane row holds entry r of the broadcast operand).  The hazard recogniser does not look inside
+// inline asm: the block opens with the wait states a DPP read of a just-written VGPR needs.
+#define SM_DOT4(R0, R1, R2, R3, acc_a, acc_b, pv, M, MB)                                                            \
+    asm("s_nop 1\n\t"                                                                                               \
+        "v_fmac_f64_dpp %0, %2, %3 row_newbcast:" #R0 " row_mask:0xf bank_mask:0xf\n\t"                             \
+        "v_fmac_f64_dpp %1, %2, %4 row_newbcast:" #R1 " row_mask:0xf bank_mask:0xf\n\t"                             \
+        "v_fmac_f64_dpp %0, %2, %5 row_newbcast:" #R2 " row_mask:0xf bank_mask:0xf\n\t"                             \
+        "v_fmac_f64_dpp %1, %2, %6 row_newbcast:" #R3 " row_mask:0xf bank_mask:0xf"                                 \
+        : "+v"(acc_a), "+v"(acc_b)                                                                                  \
+        : "v"(pv), "v"(M[MB]), "v"(M[MB + 1]), "v"(M[MB + 2]), "v"(M[MB + 3]))
+// M[MB + e] += bcast(pv, lane R_e) * x  for e = 0..3
+#define SM_AXPY4(R0, R1, R2, R3, M, MB, pv, x)                                                                      \
+    asm("s_nop 1\n\t"                                                                                               \
+        "v_fmac_f64_dpp %0, %4, %5 row_newbcast:" #R0 " row_mask:0xf bank_mask:0xf\n\t"                             \
+        "v_fmac_f64_dpp %1, %4, %5 row_newbcast:" #R1 " row_mask:0xf bank_mask:0xf\n\t"                             \
+        "v_fmac_f64_dpp %2, %4, %5 row_newbcast:" #R2 " row_mask:0xf bank_mask:0xf\n\t"                             \
+        "v_fmac_f64_dpp %3, %4, %5 row_newbcast:" #R3 " row_mask:0xf bank_mask:0xf"                                 \
+        : "+v"(M[MB]), "+v"(M[MB + 1]), "+v"(M[MB + 2]), "+v"(M[MB + 3])                                            \
+        : "v"(pv), "v"(x))
+#define SM_DOT16(acc_a, acc_b, pv, M)                                                                               \
+    SM_DOT4(0, 1, 2, 3, acc_a, acc_b, pv, M, 0); SM_DOT4(4, 5, 6, 7, acc_a, acc_b, pv, M, 4);                       \
+    SM_DOT4(8, 9, 10, 11, acc_a, acc_b, pv, M, 8); SM_DOT4(12, 13, 14, 15, acc_a, acc_b, pv, M, 12)
+#define SM_DOT8LO(acc_a, acc_b, pv, M) SM_DOT4(0, 1, 2, 3, acc_a, acc_b, pv, M, 0); SM_DOT4(4, 5, 6, 7, acc_a, acc_b, pv, M, 4)
+#define SM_DOT8HI(acc_a, acc_b, pv, M) SM_DOT4(8, 9, 10, 11, acc_a, acc_b, pv, M, 8); SM_DOT4(12, 13, 14, 15, acc_a, acc_b, pv, M, 12)
+#define SM_AXPY8LO(M, pv, x) SM_AXPY4(0, 1, 2, 3, M, 0, pv, x); SM_AXPY4(4, 5, 6, 7, M, 4, pv, x)
+#define SM_AXPY8HI(M, pv, x) SM_AXPY4(8, 9, 10, 11, M, 8, pv, x); SM_AXPY4(12, 13, 14, 15, M, 12, pv, x)
+
+// y = M v over the first k columns (8 at a time): M row in (m0: columns 0..15, m1: 16..31), v broadcast from (va, vb)
+#define SM_MATVEC(out, m0, m1, va, vb)                                                                              \
+    {                                                                                                               \
+        double s0_ = 0.0, s1_ = 0.0;                                                                                \
+        if (k > 0) { SM_DOT8LO(s0_, s1_, va, m0); }                                                                 \
+        if (k > 8) { SM_DOT8HI(s0_, s1_, va, m0); }                                                                 \
+        if (k > 16) { SM_DOT8LO(s0_, s1_, vb, m1); }                                                                \
+        if (k > 24) { SM_DOT8HI(s0_, s1_, vb, m1); }                                                                \
+        out = s0_ + s1_;                                                                                            \
+    }
+
+#ifdef DQ_SM_STAMPS
+#define SMT(v) { unsigned long long _t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t) :: "memory"); v = _t; }
+struct SmProf { unsigned long long t_pass = 0, t_acc = 0, t_dump = 0, t_hand = 0, t_first = 0; int n_pass = 0, n_acc = 0; };
+#define SM_PROF_ARG , SmProf& prof
+#define SM_PROF_PASS , prof
+#define SMX(...) __VA_ARGS__
+#else
+#define SM_PROF_ARG
+#define SM_PROF_PASS
+#define SMX(...)
+#endif
+
+// Walks one window: from proposal `pos` until KD flips are pending or the slice is over; then writes A^T, B^T, C (the
+// flush's operands) and the accepted field changes to memory.  Returns the number of flips.
+__device__ __forceinline__ int sm_walk_window(const SmShared& sh, int& pos, int n, int t, bool live, const double* __restrict__ G,
+                                              const double* __restrict__ GT, const UpdateDesc& d, long slice_off, int chain, int8_t* fields_g,
+                                              double* __restrict__ Ap, double* __restrict__ Bp, double* __restrict__ Cp SM_PROF_ARG) {
+    const int lane = t & 63, wave = t >> 6, h = lane >> 5, m = lane & 31, r16 = lane & 15;
+    SMX(unsigned long long tw0; SMT(tw0))
+    double c0[16], c1[16], t0[16], t1[16];                        // C[m][0..15], C[m][16..31], C^T[m][0..15], C^T[m][16..31] (static indices only: registers)
+    SM_DECL8(pcA); SM_DECL8(prA); SM_DECL8(pcB); SM_DECL8(prB); SM_DECL8(pcC); SM_DECL8(prC);   // prefetched G column / row elements of group (g % 3)
+    const int tt = live ? t : n - 1;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { c0[e] = 0.0; c1[e] = 0.0; t0[e] = 0.0; t1[e] = 0.0; }
+    int k = 0;
+    int g = pos >> 3;
+    bool done = false;
+    switch (g % 3) {
+        case 0: SM_LOAD8(pcA, prA, g) SM_LOAD8(pcB, prB, g + 1) break;      /* the sets of groups g and g + 1; the group macro requests g + 2 when it starts on g */
+        case 1: SM_LOAD8(pcB, prB, g) SM_LOAD8(pcC, prC, g + 1) break;
+        default: SM_LOAD8(pcC, prC, g) SM_LOAD8(pcA, prA, g + 1) break;
+    }
+#define SM_GROUP(PCS, PRS, PCT, PRT)                                                                                                     \
+    {                                                                                                                                    \
+        SM_LOAD8(PCT, PRT, g + 2)                                                                                                        \
+        const int gend = min(g * 8 + 8, n);                                                                                              \
+        while (pos < gend) {                                                                                                             \
+            /* two proposals per pass: half 0 <-> pos, half 1 <-> pos + 1 (inside the group, so the prefetch set is the same) */         \
+            SMX(unsigned long long t0_, t1_, t2_; SMT(t0_))                                                                              \
+            const bool two = pos + 1 < gend;                                                                                             \
+            const int pme = (h && two) ? pos + 1 : pos;                                                                                  \
+            const int jme = sh.site[pme];                                                                                                \
+            const int kc = max(k - 1, 0);                                                                                                \
+            /* beta = rows[:, j] and alpha = cols[:, j] in broadcast layout (lane r of every 16-lane row: entries r and 16 + r), alpha_m own */ \
+            const int o_a = min(r16, kc) * SM_LS + jme, o_b = min(16 + r16, kc) * SM_LS + jme;                                           \
+            double be_a = sh.rows[o_a], be_b = sh.rows[o_b], al_a = sh.cols[o_a], al_b = sh.cols[o_b];                                   \
+            const double d0 = sh.diag0[jme], dl = sh.dlt[pme], rb = sh.rbv[pme], uu = sh.ur[pme];                                        \
+            if (r16 >= k) { be_a = 0.0; al_a = 0.0; }                                                                                    \
+            if (16 + r16 >= k) { be_b = 0.0; al_b = 0.0; }                                                                               \
+            const double al_m = (lane & 16) ? al_b : al_a;                   /* alpha_m, m = lane & 31 */                                 \
+            double y;                                                                                                                    \
+            SM_MATVEC(y, c0, c1, be_a, be_b)                                 /* y_m = sum_n C[m][n] beta_n */                            \
+            double s = al_m * y;                                                                                                         \
+            s = row16_sum(s);                                                                                                            \
+            s += dpp_mov_f64<0x142, 0xa>(s);                                 /* row_bcast:15: rows 1 and 3 hold the sums of their halves */ \
+            const double gjj = d0 + s;                                       /* G_k[j, j] */                                              \
+            const double r = 1.0 + (1.0 - gjj) * dl;                         /* det ratio per flavour (source/model.cpp:95) */            \
+            const double R = rb * (r * r);                                   /* :121 */                                                  \
+            const bool acc_l = uu < fmin(1.0, fabs(R));                      /* bernoulli(min(1,|R|)): u < p (source/update.cpp:24) */    \
+            const unsigned long long bal = __ballot(acc_l);                                                                              \
+            const bool accA = (bal >> 31) & 1ULL, accB = two && ((bal >> 63) & 1ULL);                                                    \
+            SMX(SMT(t1_) prof.t_pass += t1_ - t0_; prof.n_pass++;)                                                                       \
+            if (!accA && !accB) { pos += two ? 2 : 1; continue; }                                                                        \
+            const int hx = accA ? 0 : 1;                                     /* the earlier proposal wins; the later one is re-evaluated */ \
+            const int p = pos + hx;                                                                                                      \
+            const int first = p - g * 8;                                                                                                 \
+            pos = p + 1;                                                                                                                 \
+            const int i = __builtin_amdgcn_readlane(jme, hx * 32 + 31);                                                                  \
+            const double pref = readlane_f64(dl, hx * 32 + 31) / readlane_f64(r, hx * 32 + 31);   /* source/model.cpp:132 */              \
+            double z;                                                                                                                    \
+            SM_MATVEC(z, t0, t1, al_a, al_b)                                 /* z_m = sum_n C[n][m] alpha_n */                           \
+            /* u~ = [y; 1], w~ = [z; 1] of the accepted half, into the broadcast layout of every row */                                  \
+            const int src = hx * 32 + r16;                                                                                               \
+            double ua = shfl_f64(y, src), ub = shfl_f64(y, src + 16), wa = shfl_f64(z, src), wb = shfl_f64(z, src + 16);                 \
+            if (r16 == (k & 15)) { if (k < 16) { ua = 1.0; wa = 1.0; } else { ub = 1.0; wb = 1.0; } }                                    \
+            const double pu = pref * ((lane & 16) ? ub : ua), pw = pref * ((lane & 16) ? wb : wa);                                       \
+            /* C[m][n] += pref u~_m w~_n,  C^T[m][n] += pref w~_m u~_n  for n <= k */                                                    \
+            SM_AXPY8LO(c0, wa, pu); SM_AXPY8LO(t0, ua, pw);                                                                              \
+            if (k >= 8) { SM_AXPY8HI(c0, wa, pu); SM_AXPY8HI(t0, ua, pw); }                                                              \
+            if (k >= 16) { SM_AXPY8LO(c1, wb, pu); SM_AXPY8LO(t1, ub, pw); }                                                             \
+            if (k >= 24) { SM_AXPY8HI(c1, wb, pu); SM_AXPY8HI(t1, ub, pw); }                                                             \
+            /* slot k of A^T / B^T: the column and the row of G0 at the flipped site, every thread its own element */                   \
+            double gc, gr;                                                                                                               \
+            SM_PICK8(PCS, PRS)                                                                                                           \
+            if (live) { sh.cols[k * SM_LS + t] = gc; sh.rows[k * SM_LS + t] = (t == i) ? gr - 1.0 : gr; }   /* V(i) -= 1 (source/model.cpp:135) */ \
+            if (t == 0) sh.acc_site[k] = p;                                                                                              \
+            ++k;                                                                                                                         \
+            lds_barrier();                                                                                                               \
+            SMX(SMT(t2_) prof.t_acc += t2_ - t1_; prof.n_acc++;)                                                                         \
+            if (k >= SM_KD) { done = true; break; }                                                                                      \
+        }                                                                                                                                \
+        if (pos >= n) done = true;                                                                                                       \
+        ++g;                                                                                                                             \
+    }
+    while (!done) {
+        switch (g % 3) {
+            case 0: SM_GROUP(pcA, prA, pcC, prC) if (done) break; [[fallthrough]];
+            case 1: SM_GROUP(pcB, prB, pcA, prA) if (done) break; [[fallthrough]];
+            default: SM_GROUP(pcC, prC, pcB, prB) break;
+        }
+    }
+#undef SM_GROUP
+    SMX(unsigned long long td0; SMT(td0))
+    // ---- window end: A^T, B^T (from LDS) and C (from the registers of wave 0) leave the workgroup ----
+    if (live) {
+        for (int mm = 0; mm < k; ++mm) { st_coh(Ap + mm * n + t, sh.cols[mm * SM_LS + t]); st_coh(Bp + mm * n + t, sh.rows[mm * SM_LS + t]); }
+    }
+    if (wave == 0 && lane < 32) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { st_coh(Cp + m * SM_KD + e, c0[e]); st_coh(Cp + m * SM_KD + 16 + e, c1[e]); }
+    }
+    if (t < k) {
+        const int p = sh.acc_site[t];
+        const int i = sh.site[p], new_f = sh.newf[p];
+        fields_g[i] = (int8_t)new_f;                                        // field.set_single_field (source/update.cpp:28)
+        d.expv[(long)chain * d.v_stride + slice_off + i] = sh.tl[24 + new_f];
+        d.invexpv[(long)chain * d.v_stride + slice_off + i] = sh.tl[28 + new_f];
+    }
+    SMX({ asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); unsigned long long td1; SMT(td1) prof.t_dump += td1 - td0; prof.t_first += td0 - tw0; })
+    return k;
+}
+static_assert(SM_KD == 32, "the sub-matrix walk keeps C as 2 x 16 register columns per lane");
+
+// One wave's share of a flush: its 16 x 16 sub-tile of G (rows a0.., columns b0..) and the mirrored sub-tile of GT.
+//   D1[nn][a] = sum_m C[m][nn] A^T[m][a]      two 16 x 16 accumulators (nn < 16, nn >= 16), 8 k-steps each
+//   G[a][b]  += sum_nn D1[nn][a] B^T[nn][b]    accumulator rows <-> b: D1's registers are the B operands
+//   GT[b][a] += the same                      accumulator rows <-> a: D1's registers are the A operands
+__device__ __forceinline__ void sm_flush_tile(double* __restrict__ G, double* __restrict__ GT, const double* __restrict__ Ap,
+                                              const double* __restrict__ Bp, const double* __restrict__ Cp, int a0, int b0, int n, int k, int lane) {
+    const int r = lane & 15, kk = lane >> 4;
+    const int a = min(a0 + r, n - 1), b = min(b0 + r, n - 1);          // clamped: loads stay unconditional
+    const bool a_ok = a0 + r < n, b_ok = b0 + r < n;
+    double av[8], bv[8], cv0[8], cv1[8], gv[4], gt[4];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const int mm = 4 * s + kk;                                     // window slot of this lane at k-step s
+        av[s] = ld_coh(Ap + mm * n + a); bv[s] = ld_coh(Bp + mm * n + b);
+        cv0[s] = ld_coh(Cp + mm * SM_KD + r); cv1[s] = ld_coh(Cp + mm * SM_KD + 16 + r);
+    }
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        const int bb = min(b0 + kk + 4 * reg, n - 1), aa = min(a0 + kk + 4 * reg, n - 1);
+        gv[reg] = ld_coh(G + a + (long)n * bb); gt[reg] = ld_coh(GT + b + (long)n * aa);
+    }
+    if (k == 0) return;
+    d4 d1lo = {0.0, 0.0, 0.0, 0.0}, d1hi = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const bool ok = 4 * s + kk < k;                                // panel rows and C rows beyond k hold stale data
+        const double am = (ok && a_ok) ? av[s] : 0.0, c_lo = ok ? cv0[s] : 0.0, c_hi = ok ? cv1[s] : 0.0;
+        d1lo = __builtin_amdgcn_mfma_f64_16x16x4f64(c_lo, am, d1lo, 0, 0, 0);       // rows <-> nn (0..15), columns <-> a
+        d1hi = __builtin_amdgcn_mfma_f64_16x16x4f64(c_hi, am, d1hi, 0, 0, 0);       // rows <-> nn (16..31)
+    }
+    d4 acc = {0.0, 0.0, 0.0, 0.0}, acc_t = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const bool ok = 4 * s + kk < k;
+        const double bm = (ok && b_ok) ? bv[s] : 0.0;
+        const double dm = s < 4 ? d1lo[s & 3] : d1hi[s & 3];           // D1[nn = 4 s + kk][a = r]
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(bm, dm, acc, 0, 0, 0);           // rows <-> b, columns <-> a
+        acc_t = __builtin_amdgcn_mfma_f64_16x16x4f64(dm, bm, acc_t, 0, 0, 0);       // rows <-> a, columns <-> b
+    }
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        const int bb = b0 + kk + 4 * reg, aa = a0 + kk + 4 * reg;
+        if (a_ok && bb < n) st_coh(G + a + (long)n * bb, gv[reg] + acc[reg]);
+        if (b_ok && aa < n) st_coh(GT + b + (long)n * aa, gt[reg] + acc_t[reg]);
+    }
+}
+
+struct SliceSync { unsigned long long seq; unsigned int arrived; unsigned int exits; unsigned int error; unsigned int pad[11]; };   // 64 B per chain (as update.hip)
+
+}  // namespace
+
+__global__ __launch_bounds__(256) void slice_sm_kernel(UpdateDesc d, SliceSync* sync_p, int l, int acc_slot, int tiles_per_dim, int* info) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int chain = blockIdx.y;
+    const int n = d.n;
+    const int F = tiles_per_dim * tiles_per_dim;
+    SliceSync* sy = sync_p + chain;
+    double* __restrict__ G = d.G.at(chain);
+    double* __restrict__ GT = d.GT.at(chain);
+    double* __restrict__ Ap = d.Upanel + (long)chain * d.panel_stride;
+    double* __restrict__ Bp = d.Wpanel + (long)chain * d.panel_stride;
+    double* __restrict__ Cp = d.Cpanel + (long)chain * (SM_KD * SM_KD);
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+
+    if (blockIdx.x > 0) {
+        // ================= flush role: one 32x32 tile of G, one 16x16 sub-tile per wave =================
+        const int tile = blockIdx.x - 1;
+        const int a0 = (tile % tiles_per_dim) * 32 + (wave & 1) * 16;
+        const int b0 = (tile / tiles_per_dim) * 32 + (wave >> 1) * 16;
+        for (unsigned win = 1;; ++win) {
+            unsigned long long word = 0; unsigned spins = 0; bool give_up = false;
+            for (;;) {
+                word = __hip_atomic_load(&sy->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((unsigned)(word >> 32) == win) break;
+                if (++spins > SM_SPIN_LIMIT) { give_up = true; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (give_up) { if (t == 0) { __hip_atomic_store(&sy->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (info) atomicOr(info, 4); } break; }
+            const int k = (int)(word & 0x7fffffffULL);
+            const bool final = (word >> 31) & 1ULL;
+            if (k > 0 && a0 < n && b0 < n) sm_flush_tile(G, GT, Ap, Bp, Cp, a0, b0, n, k, lane);
+            if (final) break;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains before the arrival is signalled
+            __syncthreads();
+            if (t == 0) __hip_atomic_fetch_add(&sy->arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    } else {
+        // ================= walk role =================
+        const bool live = t < n;
+        SmShared sh;
+        sm_shared_init(sh, smem, n);
+        const double* tab_g = reinterpret_cast<const double*>(d.tabs + chain);
+        const long slice_off = (long)l * n;
+        int8_t* fields_g = d.fields + (long)chain * d.f_stride + slice_off;
+        if (live) {
+            // proposal position t of this slice: site, old / new field value, ratio tables (source/model.cpp:99-122); none of it
+            // depends on G or on earlier flips of the slice (each site is visited once)
+            const long off = (long)chain * d.rs_stride + slice_off + t;
+            const int i = d.perm[off];
+            const int kp = d.kprop[off];
+            const int old_f = fields_g[i];
+            sh.site[t] = i; sh.newf[t] = (signed char)c_proposal_sm[old_f][kp];
+            sh.rbv[t] = tab_g[old_f * 3 + kp]; sh.dlt[t] = tab_g[12 + old_f * 3 + kp]; sh.ur[t] = d.u[off];
+            sh.diag0[t] = G[t + (long)n * t];                            // first window: G was written by the previous kernel
+        }
+        if (t < 32) sh.tl[t] = tab_g[t];
+        __syncthreads();
+        int pos = 0, total_acc = 0;
+        bool broken = false;
+        SMX(SmProf prof; unsigned long long tk0, t_hand = 0; SMT(tk0))
+        for (unsigned win = 1;; ++win) {
+            const int k = sm_walk_window(sh, pos, n, t, live, G, GT, d, slice_off, chain, fields_g, Ap, Bp, Cp SM_PROF_PASS);
+            total_acc += k;
+            const bool final = pos >= n;
+            SMX(unsigned long long th0; SMT(th0))
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // panel stores of every wave have left the CU
+            __syncthreads();
+            if (t == 0) __hip_atomic_store(&sy->seq, ((unsigned long long)win << 32) | ((unsigned long long)final << 31) | (unsigned long long)k,
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (final) break;
+            // wait until every tile has absorbed this window, then refresh the diagonal from the flushed G
+            if (wave == 0) {
+                unsigned spins = 0;
+                while (__hip_atomic_load(&sy->arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)F * win) {
+                    if (++spins > SM_SPIN_LIMIT) { broken = true; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (broken && lane == 0) { __hip_atomic_store(&sy->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (info) atomicOr(info, 4); }
+            }
+            __syncthreads();
+            if (live) sh.diag0[t] = ld_coh(G + t + (long)n * t);       // G changed: diagonal and prefetch restart from memory
+            __syncthreads();
+            SMX({ unsigned long long th1; SMT(th1) t_hand += th1 - th0; })
+        }
+        if (t == 0) d.acc_out[(long)chain * d.acc_stride + acc_slot] = total_acc;
+        SMX(if (t == 0) { unsigned long long tk1; SMT(tk1)
+            printf("sm slice l=%d: total %llu cyc | windows (walk incl. passes+accepts) %llu | %d passes %llu | %d accepts %llu | dump %llu | hand-offs %llu\n",
+                   l, tk1 - tk0, prof.t_first, prof.n_pass, prof.t_pass, prof.n_acc, prof.t_acc, prof.t_dump, t_hand); })
+    }
+    // exit ticket: the last workgroup of the chain to leave re-arms the sync words for the next launch
+    __syncthreads();
+    if (t == 0) {
+        const unsigned ticket = __hip_atomic_fetch_add(&sy->exits, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (ticket == (unsigned)F) {
+            __hip_atomic_store(&sy->seq, 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&sy->arrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&sy->exits, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+int update_sm_init_device() {
+    DQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(slice_sm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    return 0;
+}
+
+// the whole local update of time slice l in one launch (caller: launch_update_slice, which has checked n <= 256, GT valid, reservation held)
+int launch_update_slice_sm(const UpdateDesc& d, int l, int acc_slot, int n_chains, hipStream_t s) {
+    const int n = d.n;
+    if (n > 256 || !d.Cpanel || !d.slice_sync || !d.GT.p) { set_error("sub-matrix slice kernel: n <= 256, panel / sync / transposed workspaces required"); return -1; }
+    const int tiles = (n + 31) / 32;
+    hipLaunchKernelGGL(slice_sm_kernel, dim3(1 + tiles * tiles, n_chains), dim3(256), sm_lds_bytes(n), s, d, reinterpret_cast<SliceSync*>(d.slice_sync), l, acc_slot,
+                       tiles, d.info);
+    DQ_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace dq

@@ -193,28 +193,3 @@ def test_results_k_space_of_a_delta_is_flat(host, tmp_path):
     assert rc == 0, err.value
     dk = _h5_read(h, str(tmp_path / "data_0.h5"), "/binK_0/equaltime/densityCorr")
     np.testing.assert_allclose(dk[..., 0], 1.0, atol=1e-14); np.testing.assert_allclose(dk[..., 1], 0.0, atol=1e-14)
-
-
-def test_results_summary_script_reads_what_the_writer_wrote(host, tmp_path):
-    """scripts/results_summary.py (the h5py-free stand-in for the scalar part of the reference's scripts/analysis.py): bins of two
-    rank files are concatenated, mean and standard error per observable."""
-    import importlib.util
-    h = host
-    h.dqmc_host_results_write.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_char_p, C.c_int]
-    L1 = L2 = 4; rng = np.random.default_rng(8); err = C.create_string_buffer(256)
-    allsc = []
-    for rank, nb in ((0, 3), (1, 2)):
-        sc = rng.normal(size=(nb, 3)); chi = rng.normal(size=(nb, L1 * L2)); allsc.append(sc)
-        rc = h.dqmc_host_results_write(str(tmp_path).encode(), rank, L1, L2, nb, sc.ctypes.data, chi.ctypes.data, None, 0, err, 256)
-        if rc != 0 and b"libhdf5 not found" in err.value:
-            pytest.skip("no libhdf5 on this machine")
-        assert rc == 0, err.value
-    spec = importlib.util.spec_from_file_location("results_summary", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "results_summary.py"))
-    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
-    bins = mod.load_bins(str(tmp_path))
-    allsc = np.concatenate(allsc)
-    assert bins["scalar/density"].shape == (5,) and bins["equaltime/densityCorr"].shape == (5, L1, L2, 1)
-    np.testing.assert_array_equal(bins["scalar/swave"], allsc[:, 2])
-    m, e = mod.mean_and_stderr(bins["scalar/doubleOcc"])
-    assert abs(m - allsc[:, 1].mean()) < 1e-15 and abs(e - allsc[:, 1].std(ddof=1) / np.sqrt(5)) < 1e-15
-    assert "unequaltime/greenTau" not in bins
