@@ -91,6 +91,7 @@ __global__ __launch_bounds__(QC_T) void qrcp_coop_kernel(Mat Am, QrWork w, int n
     unsigned wlive;                                    // bit q: local column q is live (same in every thread)
     { const int cnt = n - QC_COLS * wg; wlive = cnt >= 32 ? 0xFFFFFFFFu : (cnt > 0 ? ((1u << cnt) - 1u) : 0u); }
     if (t < QC_COLS) pposl[t] = 1 << 30;
+    for (int r = n + t; r < 16 * NB; r += QC_T) { xbuf[r] = 0.0; vbuf[r] = 0.0; }      // padding rows: read (times a zero matrix entry) but never written
 
     // ---- load my columns, initial norms (every lane q < 32 of every wave keeps the norm of local column q) ----
     double nrm1 = 0.0, nrm2 = 0.0;                      // vn1 / vn2 of local column (lane & 31), valid in lanes 0..31
