@@ -169,6 +169,7 @@ constexpr int UPDATE_KD = 32;    // delayed-update window (accepted flips per fl
 int launch_update_slice(const UpdateDesc& d, int l, int acc_slot, int n_chains, hipStream_t s);
 // sub-matrix variant of the persistent single-launch slice kernel (update_sm.hip)
 int launch_update_slice_sm(const UpdateDesc& d, int l, int acc_slot, int n_chains, hipStream_t s);
+int slice_flush_workgroups(int n);        // flush workgroups per chain of the persistent slice kernels
 // CU reservation for the persistent single-launch slice kernel (see update.hip); an engine that holds one passes slice_sync
 bool slice_reserve(int device, int n, int n_chains);
 void slice_release(int device, int n, int n_chains);

@@ -353,15 +353,17 @@ struct Engine {
     // DQMC::propagate_GF_forward (source/dqmc.cpp:113-132): G = B_l G B_l^-1
     int wrap_forward(int l) {
         DQ_TRY(ctx.gemm(CMat(expK, nn), mG(), ctx.T(0)));
-        gt_valid = n <= 256;                                          // the GEMM that writes G writes GT as well
-        return ctx.gemm(ctx.T(0), CMat(invexpK, nn), mG(), ev(l), CVec(), iev(l), 0, 0, n <= 256 ? Mat{GT, nn} : Mat{nullptr, 0});
+        gt_valid = use_gt();                                          // the GEMM that writes G writes GT as well
+        return ctx.gemm(ctx.T(0), CMat(invexpK, nn), mG(), ev(l), CVec(), iev(l), 0, 0, use_gt() ? Mat{GT, nn} : Mat{nullptr, 0});
     }
     // DQMC::propagate_GF_backward (source/dqmc.cpp:169-187): G = B_l^-1 G B_l
     int wrap_backward(int l) {
         DQ_TRY(ctx.gemm(CMat(invexpK, nn), mG(), ctx.T(0), CVec(), iev(l)));
-        gt_valid = n <= 256;
-        return ctx.gemm(ctx.T(0), CMat(expK, nn), mG(), CVec(), ev(l), CVec(), 0, 0, n <= 256 ? Mat{GT, nn} : Mat{nullptr, 0});
+        gt_valid = use_gt();
+        return ctx.gemm(ctx.T(0), CMat(expK, nn), mG(), CVec(), ev(l), CVec(), 0, 0, use_gt() ? Mat{GT, nn} : Mat{nullptr, 0});
     }
+    // the walk reads rows of G from a transposed copy: the register walk (n <= 256) and the persistent sub-matrix kernel (any n)
+    bool use_gt() const { return n <= 256 || persistent; }
     UpdateDesc udesc() const {
         UpdateDesc d; d.G = mG(); d.fields = fields; d.f_stride = (long)nt * n; d.expv = expv; d.invexpv = invexpv; d.v_stride = (long)nt * n;
         d.tabs = tabs; d.perm = rs_perm; d.kprop = rs_k; d.u = rs_u; d.rs_stride = (long)nt * n; d.Upanel = Upanel; d.Wpanel = Wpanel; d.Cpanel = Cpanel;

@@ -796,9 +796,9 @@ static int pick_kd(int n) {
 static std::mutex g_resv_mu;
 static int g_resv_used[64] = {};
 static int g_resv_cap[64] = {};
-int slice_workgroups(int n, int n_chains) { const int tiles = (n + 31) / 32; return (1 + tiles * tiles) * n_chains; }
+int slice_workgroups(int n, int n_chains) { return (1 + slice_flush_workgroups(n)) * n_chains; }
 bool slice_reserve(int device, int n, int n_chains) {
-    if (device < 0 || device >= 64 || n > 256) return false;
+    if (device < 0 || device >= 64 || n > 1024) return false;
     std::lock_guard<std::mutex> lk(g_resv_mu);
     if (g_resv_cap[device] == 0) {
         hipDeviceProp_t prop;
@@ -844,7 +844,10 @@ int launch_update_slice(const UpdateDesc& d, int l, int acc_slot, int n_chains, 
     // Opt-in: measured 211 us per cfg-3 slice against 138 us for the delayed-update walk below -- the k x k algebra is a dependent chain
     // on one wave per SIMD (860 clk per two-proposal pass, 1780 clk per accepted flip), see DESIGN.md
     static const bool submatrix_walk = getenv("DQMC_WALK_SUBMATRIX") != nullptr;
-    if (!multi_kernel && regs && d.slice_sync && d.Cpanel && submatrix_walk) return launch_update_slice_sm(d, l, acc_slot, n_chains, s);
+    if (!multi_kernel && d.slice_sync && d.Cpanel && d.GT.p && (submatrix_walk || !regs)) {       // n > 256: the default (see update_sm.hip)
+        if (!regs && !d.gt_valid) { if (int rc = launch_transpose_scale(CMat(d.G.p, d.G.stride), d.GT, CVec(), n, n_chains, s)) return rc; }
+        return launch_update_slice_sm(d, l, acc_slot, n_chains, s);
+    }
     if (!multi_kernel && regs && d.slice_sync) {                    // slice_sync is only handed out with a CU reservation (slice_reserve)
         hipLaunchKernelGGL(slice_kernel, dim3(1 + tiles * tiles, n_chains), dim3(256), lds, s, d, reinterpret_cast<SliceSync*>(d.slice_sync), l, acc_slot, kd,
                            tiles, d.info);

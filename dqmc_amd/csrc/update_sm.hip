@@ -1,7 +1,10 @@
 // update_sm.hip -- update::local_update (source/update.cpp:5-32) for one time slice with SUB-MATRIX updates: the
 // second of the two speed-ups the reference's README lists as future work ("delayed / sub-matrix updates",
-// README.md:41).  Persistent single-launch kernel for n <= 256 and few chains; the
-// delayed-update kernels of update.hip remain the path for batched engines and n > 256.
+// README.md:41).  Persistent single-launch kernel for n <= 1024 and few chains.  It is the default
+// for 256 < n <= 1024 (the per-proposal cost of the k x k algebra does not grow with n, where the delayed update's
+// 2 n k flops per accepted flip and its scan / flush launch pairs do: 0.44 ms against 1.65 ms per cfg-5 slice) and opt-in
+// (DQMC_WALK_SUBMATRIX=1) at n <= 256, where the register-resident delayed-update walk of update.hip is faster; batched
+// engines keep the delayed-update kernels.
 //
 // Within a window of up to KD = 32 accepted flips at sites S = (s_1 .. s_k) the Green's function is never touched.
 // Every accepted flip is a rank-1 change (AttractiveHubbard::update_greens_local, source/model.cpp:124-138) whose
@@ -17,7 +20,7 @@
 // When the window closes,  G += (A C) B^T  is applied by the flush workgroups on the matrix cores.  The Markov chain
 // is the reference's; only the rounding order differs (1e-14 against the sequential rank-1 form, tests/test_oracle.py).
 //
-// Walk workgroup (256 threads, one wave per SIMD, thread t <-> site t):
+// Walk workgroup (256 threads, one wave per SIMD, thread t <-> sites t, t + 256, ... : NS = ceil(n / 256) site slots):
 //   * LDS holds A^T and B^T of the window: cols[m][t] = G0[t, s_m], rows[m][t] = G0[s_m, t] - [t == s_m], written by
 //     all threads when flip m is accepted from the column / row elements every thread prefetches for every proposal
 //     (as in the delayed-update walk; G0 does not change inside a window, so the prefetch is exact);
@@ -43,9 +46,10 @@ using d4 = __attribute__((ext_vector_type(4))) double;
 
 __constant__ int c_proposal_sm[4][3] = {{1, 2, 3}, {0, 2, 3}, {0, 1, 3}, {0, 1, 2}};   // include/field.h:45-48
 
-constexpr int SM_KD = UPDATE_KD;               // window: 2 x 16 broadcast slots per 16-lane row
-constexpr int SM_LS = 257;                     // LDS row stride of cols / rows (doubles): rows m = 0..15 land in distinct banks
+constexpr int SM_KD = UPDATE_KD;               // largest window: 2 x 16 broadcast slots per 16-lane row
 constexpr unsigned SM_SPIN_LIMIT = 1u << 20;
+// LDS row stride of cols / rows (doubles), = 1 mod 32: rows m = 0..15 of one column land in distinct banks
+__host__ __device__ inline int sm_ls(int n) { return ((n + 31) / 32) * 32 + 1; }
 
 __device__ __forceinline__ double ld_coh(const double* p) {
     return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
@@ -66,43 +70,59 @@ __device__ __forceinline__ double shfl_f64(double x, int src_lane) {
 }
 
 struct SmShared {
-    double* cols; double* rows;                 // [KD][SM_LS]
+    double* cols; double* rows;                 // [kd][ls]
+    int ls;
     double* diag0; double* dlt; double* rbv; double* ur; double* tl;
     int* site; signed char* newf; int* acc_site;
 };
-__host__ __device__ inline size_t sm_lds_bytes(int n) {
-    return (size_t)2 * SM_KD * SM_LS * 8 + (size_t)n * 32 + 256 + (size_t)n * 4 + (((size_t)n + 7) & ~(size_t)7) + SM_KD * 4 + 64;
+__host__ __device__ inline size_t sm_fixed_bytes(int n) { return (size_t)n * 32 + 256 + (size_t)n * 4 + (((size_t)n + 7) & ~(size_t)7) + SM_KD * 4 + 64; }
+__host__ __device__ inline size_t sm_lds_bytes(int n, int kd) { return (size_t)2 * kd * sm_ls(n) * 8 + sm_fixed_bytes(n); }
+// window size the 160 KiB of LDS allow: A^T and B^T of the window are kd x n each
+__host__ __device__ inline int sm_pick_kd(int n) {
+    const long room = 160L * 1024 - (long)sm_fixed_bytes(n) - 256;
+    long kd = room / (16L * sm_ls(n));
+    return (int)(kd > SM_KD ? SM_KD : kd < 1 ? 1 : kd);
 }
-__device__ __forceinline__ void sm_shared_init(SmShared& sh, unsigned char* smem, int n) {
+__device__ __forceinline__ void sm_shared_init(SmShared& sh, unsigned char* smem, int n, int kd) {
+    sh.ls = sm_ls(n);
     sh.cols = reinterpret_cast<double*>(smem);
-    sh.rows = sh.cols + SM_KD * SM_LS;
-    sh.diag0 = sh.rows + SM_KD * SM_LS;
+    sh.rows = sh.cols + kd * sh.ls;
+    sh.diag0 = sh.rows + kd * sh.ls;
     sh.dlt = sh.diag0 + n; sh.rbv = sh.dlt + n; sh.ur = sh.rbv + n; sh.tl = sh.ur + n;
     sh.site = reinterpret_cast<int*>(sh.tl + 32);
     sh.newf = reinterpret_cast<signed char*>(sh.site + n);
     sh.acc_site = reinterpret_cast<int*>(sh.newf + ((n + 7) & ~7));
 }
 
-// G[t, site] (PC##q) and G[site, t] (PR##q, from the transposed copy) of the 8 proposals of group gg, thread t.  The sixteen values
-// of a group are SCALARS named by token pasting, not arrays: the accepted proposal's pair is selected by a switch, and with arrays
+// G[tt, site] (PC##q##_sl) and G[site, tt] (PR##q##_sl, from the transposed copy) of the 8 proposals of group gg for the thread's site
+// slots sl (tt = t + 256 sl).  The values of a group are SCALARS named by token pasting, not arrays: the accepted proposal's pair is selected by a switch, and with arrays
 // the optimiser folds that switch into one dynamically indexed load, which pins all three register sets in scratch.
-#define SM_DECL8(P) double P##0 = 0.0, P##1 = 0.0, P##2 = 0.0, P##3 = 0.0, P##4 = 0.0, P##5 = 0.0, P##6 = 0.0, P##7 = 0.0
+#define SM_DECL1(P, q) double P##q##_0 = 0.0, P##q##_1 = 0.0, P##q##_2 = 0.0, P##q##_3 = 0.0
+#define SM_DECL8(P) SM_DECL1(P, 0); SM_DECL1(P, 1); SM_DECL1(P, 2); SM_DECL1(P, 3); SM_DECL1(P, 4); SM_DECL1(P, 5); SM_DECL1(P, 6); SM_DECL1(P, 7)
+#define SM_LOADS(PC, PR, q, sl)                                                                                     \
+    {                                                                                                               \
+        const unsigned off8_ = (unsigned)(tt##sl + n * i_) * 8u;                                                    \
+        PC##q##_##sl = ld_coh(reinterpret_cast<const double*>(reinterpret_cast<const char*>(G) + off8_));           \
+        PR##q##_##sl = ld_coh(reinterpret_cast<const double*>(reinterpret_cast<const char*>(GT) + off8_));          \
+    }
 #define SM_LOAD1(PC, PR, gg, q)                                                                                     \
     {                                                                                                               \
         const int i_ = sh.site[min((gg) * 8 + q, n - 1)];             /* clamped: loads stay unconditional */       \
-        const unsigned off8_ = (unsigned)(tt + n * i_) * 8u;                                                        \
-        PC##q = ld_coh(reinterpret_cast<const double*>(reinterpret_cast<const char*>(G) + off8_));                  \
-        PR##q = ld_coh(reinterpret_cast<const double*>(reinterpret_cast<const char*>(GT) + off8_));                 \
+        SM_LOADS(PC, PR, q, 0)                                                                                      \
+        if constexpr (NS > 1) SM_LOADS(PC, PR, q, 1)                                                                \
+        if constexpr (NS > 2) SM_LOADS(PC, PR, q, 2)                                                                \
+        if constexpr (NS > 3) SM_LOADS(PC, PR, q, 3)                                                                \
     }
 #define SM_LOAD8(PC, PR, gg)                                                                                        \
     SM_LOAD1(PC, PR, gg, 0) SM_LOAD1(PC, PR, gg, 1) SM_LOAD1(PC, PR, gg, 2) SM_LOAD1(PC, PR, gg, 3)                 \
     SM_LOAD1(PC, PR, gg, 4) SM_LOAD1(PC, PR, gg, 5) SM_LOAD1(PC, PR, gg, 6) SM_LOAD1(PC, PR, gg, 7)
+#define SM_PICK1(PC, PR, q) gc0 = PC##q##_0; gr0 = PR##q##_0; gc1 = PC##q##_1; gr1 = PR##q##_1; gc2 = PC##q##_2; gr2 = PR##q##_2; gc3 = PC##q##_3; gr3 = PR##q##_3;
 #define SM_PICK8(PC, PR)                                                                                            \
     switch (first) {                                                                                                \
-        case 0: gc = PC##0; gr = PR##0; break; case 1: gc = PC##1; gr = PR##1; break;                               \
-        case 2: gc = PC##2; gr = PR##2; break; case 3: gc = PC##3; gr = PR##3; break;                               \
-        case 4: gc = PC##4; gr = PR##4; break; case 5: gc = PC##5; gr = PR##5; break;                               \
-        case 6: gc = PC##6; gr = PR##6; break; default: gc = PC##7; gr = PR##7; break;                              \
+        case 0: SM_PICK1(PC, PR, 0) break; case 1: SM_PICK1(PC, PR, 1) break;                                       \
+        case 2: SM_PICK1(PC, PR, 2) break; case 3: SM_PICK1(PC, PR, 3) break;                                       \
+        case 4: SM_PICK1(PC, PR, 4) break; case 5: SM_PICK1(PC, PR, 5) break;                                       \
+        case 6: SM_PICK1(PC, PR, 6) break; default: SM_PICK1(PC, PR, 7) break;                                      \
     }
 
 // acc_a += bcast(pv, lane R0) * M[MB] + bcast(pv, R2) * M[MB + 2];  acc_b += bcast(pv, R1) * M[MB + 1] + bcast(pv, R3) * M[MB + 3]
@@ -158,27 +178,37 @@ struct SmProf { unsigned long long t_pass = 0, t_acc = 0, t_dump = 0, t_hand = 0
 
 // Walks one window: from proposal `pos` until KD flips are pending or the slice is over; then writes A^T, B^T, C (the
 // flush's operands) and the accepted field changes to memory.  Returns the number of flips.
-__device__ __forceinline__ int sm_walk_window(const SmShared& sh, int& pos, int n, int t, bool live, const double* __restrict__ G,
+template <int NS>
+__device__ __forceinline__ int sm_walk_window(const SmShared& sh, int& pos, int n, int kd, int t, const double* __restrict__ G,
                                               const double* __restrict__ GT, const UpdateDesc& d, long slice_off, int chain, int8_t* fields_g,
                                               double* __restrict__ Ap, double* __restrict__ Bp, double* __restrict__ Cp SM_PROF_ARG) {
     const int lane = t & 63, wave = t >> 6, h = lane >> 5, m = lane & 31, r16 = lane & 15;
     SMX(unsigned long long tw0; SMT(tw0))
     double c0[16], c1[16], t0[16], t1[16];                        // C[m][0..15], C[m][16..31], C^T[m][0..15], C^T[m][16..31] (static indices only: registers)
     SM_DECL8(pcA); SM_DECL8(prA); SM_DECL8(pcB); SM_DECL8(prB); SM_DECL8(pcC); SM_DECL8(prC);   // prefetched G column / row elements of group (g % 3)
-    const int tt = live ? t : n - 1;
+    const int tt0 = min(t, n - 1), tt1 = min(t + 256, n - 1), tt2 = min(t + 512, n - 1), tt3 = min(t + 768, n - 1);   // clamped site slots
+    (void)tt1; (void)tt2; (void)tt3;
+    const int LS = sh.ls;
 #pragma unroll
     for (int e = 0; e < 16; ++e) { c0[e] = 0.0; c1[e] = 0.0; t0[e] = 0.0; t1[e] = 0.0; }
     int k = 0;
     int g = pos >> 3;
     bool done = false;
-    switch (g % 3) {
-        case 0: SM_LOAD8(pcA, prA, g) SM_LOAD8(pcB, prB, g + 1) break;      /* the sets of groups g and g + 1; the group macro requests g + 2 when it starts on g */
-        case 1: SM_LOAD8(pcB, prB, g) SM_LOAD8(pcC, prC, g + 1) break;
-        default: SM_LOAD8(pcC, prC, g) SM_LOAD8(pcA, prA, g + 1) break;
+    // NS <= 2: three register sets, the loads of groups g + 1 and g + 2 in flight while group g is walked; NS >= 3 (n > 512): two
+    // sets (a third would not fit the register file), the loads of group g + 1 in flight -- a group takes >= 4 passes = 1.4 us
+    constexpr int LEAD = NS <= 2 ? 2 : 1;
+    if constexpr (NS <= 2) {
+        switch (g % 3) {
+            case 0: SM_LOAD8(pcA, prA, g) SM_LOAD8(pcB, prB, g + 1) break;      /* the sets of groups g and g + 1; the group macro requests g + 2 when it starts on g */
+            case 1: SM_LOAD8(pcB, prB, g) SM_LOAD8(pcC, prC, g + 1) break;
+            default: SM_LOAD8(pcC, prC, g) SM_LOAD8(pcA, prA, g + 1) break;
+        }
+    } else {
+        if (g % 2 == 0) { SM_LOAD8(pcA, prA, g) } else { SM_LOAD8(pcB, prB, g) }
     }
 #define SM_GROUP(PCS, PRS, PCT, PRT)                                                                                                     \
     {                                                                                                                                    \
-        SM_LOAD8(PCT, PRT, g + 2)                                                                                                        \
+        SM_LOAD8(PCT, PRT, g + LEAD)                                                                                                     \
         const int gend = min(g * 8 + 8, n);                                                                                              \
         while (pos < gend) {                                                                                                             \
             /* two proposals per pass: half 0 <-> pos, half 1 <-> pos + 1 (inside the group, so the prefetch set is the same) */         \
@@ -188,7 +218,7 @@ __device__ __forceinline__ int sm_walk_window(const SmShared& sh, int& pos, int 
             const int jme = sh.site[pme];                                                                                                \
             const int kc = max(k - 1, 0);                                                                                                \
             /* beta = rows[:, j] and alpha = cols[:, j] in broadcast layout (lane r of every 16-lane row: entries r and 16 + r), alpha_m own */ \
-            const int o_a = min(r16, kc) * SM_LS + jme, o_b = min(16 + r16, kc) * SM_LS + jme;                                           \
+            const int o_a = min(r16, kc) * LS + jme, o_b = min(16 + r16, kc) * LS + jme;                                              \
             double be_a = sh.rows[o_a], be_b = sh.rows[o_b], al_a = sh.cols[o_a], al_b = sh.cols[o_b];                                   \
             const double d0 = sh.diag0[jme], dl = sh.dlt[pme], rb = sh.rbv[pme], uu = sh.ur[pme];                                        \
             if (r16 >= k) { be_a = 0.0; al_a = 0.0; }                                                                                    \
@@ -226,31 +256,39 @@ __device__ __forceinline__ int sm_walk_window(const SmShared& sh, int& pos, int 
             if (k >= 16) { SM_AXPY8LO(c1, wb, pu); SM_AXPY8LO(t1, ub, pw); }                                                             \
             if (k >= 24) { SM_AXPY8HI(c1, wb, pu); SM_AXPY8HI(t1, ub, pw); }                                                             \
             /* slot k of A^T / B^T: the column and the row of G0 at the flipped site, every thread its own element */                   \
-            double gc, gr;                                                                                                               \
+            double gc0, gr0, gc1, gr1, gc2, gr2, gc3, gr3;                                                                               \
             SM_PICK8(PCS, PRS)                                                                                                           \
-            if (live) { sh.cols[k * SM_LS + t] = gc; sh.rows[k * SM_LS + t] = (t == i) ? gr - 1.0 : gr; }   /* V(i) -= 1 (source/model.cpp:135) */ \
+            /* V(i) -= 1 (source/model.cpp:135) */                                                                                       \
+            if (t < n) { sh.cols[k * LS + t] = gc0; sh.rows[k * LS + t] = (t == i) ? gr0 - 1.0 : gr0; }                                  \
+            if (NS > 1 && t + 256 < n) { sh.cols[k * LS + t + 256] = gc1; sh.rows[k * LS + t + 256] = (t + 256 == i) ? gr1 - 1.0 : gr1; } \
+            if (NS > 2 && t + 512 < n) { sh.cols[k * LS + t + 512] = gc2; sh.rows[k * LS + t + 512] = (t + 512 == i) ? gr2 - 1.0 : gr2; } \
+            if (NS > 3 && t + 768 < n) { sh.cols[k * LS + t + 768] = gc3; sh.rows[k * LS + t + 768] = (t + 768 == i) ? gr3 - 1.0 : gr3; } \
             if (t == 0) sh.acc_site[k] = p;                                                                                              \
             ++k;                                                                                                                         \
             lds_barrier();                                                                                                               \
             SMX(SMT(t2_) prof.t_acc += t2_ - t1_; prof.n_acc++;)                                                                         \
-            if (k >= SM_KD) { done = true; break; }                                                                                      \
+            if (k >= kd) { done = true; break; }                                                                                      \
         }                                                                                                                                \
         if (pos >= n) done = true;                                                                                                       \
         ++g;                                                                                                                             \
     }
     while (!done) {
-        switch (g % 3) {
-            case 0: SM_GROUP(pcA, prA, pcC, prC) if (done) break; [[fallthrough]];
-            case 1: SM_GROUP(pcB, prB, pcA, prA) if (done) break; [[fallthrough]];
-            default: SM_GROUP(pcC, prC, pcB, prB) break;
+        if constexpr (NS <= 2) {
+            switch (g % 3) {
+                case 0: SM_GROUP(pcA, prA, pcC, prC) if (done) break; [[fallthrough]];
+                case 1: SM_GROUP(pcB, prB, pcA, prA) if (done) break; [[fallthrough]];
+                default: SM_GROUP(pcC, prC, pcB, prB) break;
+            }
+        } else {
+            if (g % 2 == 0) { SM_GROUP(pcA, prA, pcB, prB) if (done) break; }
+            SM_GROUP(pcB, prB, pcA, prA)
         }
     }
 #undef SM_GROUP
     SMX(unsigned long long td0; SMT(td0))
     // ---- window end: A^T, B^T (from LDS) and C (from the registers of wave 0) leave the workgroup ----
-    if (live) {
-        for (int mm = 0; mm < k; ++mm) { st_coh(Ap + mm * n + t, sh.cols[mm * SM_LS + t]); st_coh(Bp + mm * n + t, sh.rows[mm * SM_LS + t]); }
-    }
+    for (int tt = t; tt < n; tt += 256)
+        for (int mm = 0; mm < k; ++mm) { st_coh(Ap + mm * n + tt, sh.cols[mm * LS + tt]); st_coh(Bp + mm * n + tt, sh.rows[mm * LS + tt]); }
     if (wave == 0 && lane < 32) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) { st_coh(Cp + m * SM_KD + e, c0[e]); st_coh(Cp + m * SM_KD + 16 + e, c1[e]); }
@@ -266,6 +304,8 @@ __device__ __forceinline__ int sm_walk_window(const SmShared& sh, int& pos, int 
     return k;
 }
 static_assert(SM_KD == 32, "the sub-matrix walk keeps C as 2 x 16 register columns per lane");
+#undef SM_DECL1
+#undef SM_DECL8
 
 // One wave's share of a flush: its 16 x 16 sub-tile of G (rows a0.., columns b0..) and the mirrored sub-tile of GT.
 //   D1[nn][a] = sum_m C[m][nn] A^T[m][a]      two 16 x 16 accumulators (nn < 16, nn >= 16), 8 k-steps each
@@ -318,11 +358,15 @@ struct SliceSync { unsigned long long seq; unsigned int arrived; unsigned int ex
 
 }  // namespace
 
-__global__ __launch_bounds__(256) void slice_sm_kernel(UpdateDesc d, SliceSync* sync_p, int l, int acc_slot, int tiles_per_dim, int* info) {
+// grid = (1 + Fwg, chains): workgroup 0 walks, workgroups 1 .. Fwg flush; flush workgroup f owns the 32 x 32 tiles f, f + Fwg, ...
+// of G and GT (one tile each while tiles^2 <= 192; two each at n = 576)
+template <int NS>
+__global__ __launch_bounds__(256) void slice_sm_kernel(UpdateDesc d, SliceSync* sync_p, int l, int acc_slot, int tiles_per_dim, int kd, int* info) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int chain = blockIdx.y;
     const int n = d.n;
-    const int F = tiles_per_dim * tiles_per_dim;
+    const int F = (int)gridDim.x - 1;                                 // flush workgroups
+    const int n_tiles = tiles_per_dim * tiles_per_dim;
     SliceSync* sy = sync_p + chain;
     double* __restrict__ G = d.G.at(chain);
     double* __restrict__ GT = d.GT.at(chain);
@@ -332,10 +376,7 @@ __global__ __launch_bounds__(256) void slice_sm_kernel(UpdateDesc d, SliceSync* 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
 
     if (blockIdx.x > 0) {
-        // ================= flush role: one 32x32 tile of G, one 16x16 sub-tile per wave =================
-        const int tile = blockIdx.x - 1;
-        const int a0 = (tile % tiles_per_dim) * 32 + (wave & 1) * 16;
-        const int b0 = (tile / tiles_per_dim) * 32 + (wave >> 1) * 16;
+        // ================= flush role: 32x32 tiles of G, one 16x16 sub-tile per wave =================
         for (unsigned win = 1;; ++win) {
             unsigned long long word = 0; unsigned spins = 0; bool give_up = false;
             for (;;) {
@@ -347,7 +388,13 @@ __global__ __launch_bounds__(256) void slice_sm_kernel(UpdateDesc d, SliceSync* 
             if (give_up) { if (t == 0) { __hip_atomic_store(&sy->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (info) atomicOr(info, 4); } break; }
             const int k = (int)(word & 0x7fffffffULL);
             const bool final = (word >> 31) & 1ULL;
-            if (k > 0 && a0 < n && b0 < n) sm_flush_tile(G, GT, Ap, Bp, Cp, a0, b0, n, k, lane);
+            if (k > 0) {
+                for (int tile = (int)blockIdx.x - 1; tile < n_tiles; tile += F) {
+                    const int a0 = (tile % tiles_per_dim) * 32 + (wave & 1) * 16;
+                    const int b0 = (tile / tiles_per_dim) * 32 + (wave >> 1) * 16;
+                    if (a0 < n && b0 < n) sm_flush_tile(G, GT, Ap, Bp, Cp, a0, b0, n, k, lane);
+                }
+            }
             if (final) break;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains before the arrival is signalled
             __syncthreads();
@@ -355,22 +402,21 @@ __global__ __launch_bounds__(256) void slice_sm_kernel(UpdateDesc d, SliceSync* 
         }
     } else {
         // ================= walk role =================
-        const bool live = t < n;
         SmShared sh;
-        sm_shared_init(sh, smem, n);
+        sm_shared_init(sh, smem, n, kd);
         const double* tab_g = reinterpret_cast<const double*>(d.tabs + chain);
         const long slice_off = (long)l * n;
         int8_t* fields_g = d.fields + (long)chain * d.f_stride + slice_off;
-        if (live) {
-            // proposal position t of this slice: site, old / new field value, ratio tables (source/model.cpp:99-122); none of it
+        for (int tt = t; tt < n; tt += 256) {
+            // proposal position tt of this slice: site, old / new field value, ratio tables (source/model.cpp:99-122); none of it
             // depends on G or on earlier flips of the slice (each site is visited once)
-            const long off = (long)chain * d.rs_stride + slice_off + t;
+            const long off = (long)chain * d.rs_stride + slice_off + tt;
             const int i = d.perm[off];
             const int kp = d.kprop[off];
             const int old_f = fields_g[i];
-            sh.site[t] = i; sh.newf[t] = (signed char)c_proposal_sm[old_f][kp];
-            sh.rbv[t] = tab_g[old_f * 3 + kp]; sh.dlt[t] = tab_g[12 + old_f * 3 + kp]; sh.ur[t] = d.u[off];
-            sh.diag0[t] = G[t + (long)n * t];                            // first window: G was written by the previous kernel
+            sh.site[tt] = i; sh.newf[tt] = (signed char)c_proposal_sm[old_f][kp];
+            sh.rbv[tt] = tab_g[old_f * 3 + kp]; sh.dlt[tt] = tab_g[12 + old_f * 3 + kp]; sh.ur[tt] = d.u[off];
+            sh.diag0[tt] = G[tt + (long)n * tt];                         // first window: G was written by the previous kernel
         }
         if (t < 32) sh.tl[t] = tab_g[t];
         __syncthreads();
@@ -378,7 +424,7 @@ __global__ __launch_bounds__(256) void slice_sm_kernel(UpdateDesc d, SliceSync* 
         bool broken = false;
         SMX(SmProf prof; unsigned long long tk0, t_hand = 0; SMT(tk0))
         for (unsigned win = 1;; ++win) {
-            const int k = sm_walk_window(sh, pos, n, t, live, G, GT, d, slice_off, chain, fields_g, Ap, Bp, Cp SM_PROF_PASS);
+            const int k = sm_walk_window<NS>(sh, pos, n, kd, t, G, GT, d, slice_off, chain, fields_g, Ap, Bp, Cp SM_PROF_PASS);
             total_acc += k;
             const bool final = pos >= n;
             SMX(unsigned long long th0; SMT(th0))
@@ -387,7 +433,7 @@ __global__ __launch_bounds__(256) void slice_sm_kernel(UpdateDesc d, SliceSync* 
             if (t == 0) __hip_atomic_store(&sy->seq, ((unsigned long long)win << 32) | ((unsigned long long)final << 31) | (unsigned long long)k,
                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (final) break;
-            // wait until every tile has absorbed this window, then refresh the diagonal from the flushed G
+            // wait until every flush workgroup has absorbed this window, then refresh the diagonal from the flushed G
             if (wave == 0) {
                 unsigned spins = 0;
                 while (__hip_atomic_load(&sy->arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)F * win) {
@@ -397,7 +443,7 @@ __global__ __launch_bounds__(256) void slice_sm_kernel(UpdateDesc d, SliceSync* 
                 if (broken && lane == 0) { __hip_atomic_store(&sy->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (info) atomicOr(info, 4); }
             }
             __syncthreads();
-            if (live) sh.diag0[t] = ld_coh(G + t + (long)n * t);       // G changed: diagonal and prefetch restart from memory
+            for (int tt = t; tt < n; tt += 256) sh.diag0[tt] = ld_coh(G + tt + (long)n * tt);       // G changed: diagonal and prefetch restart from memory
             __syncthreads();
             SMX({ unsigned long long th1; SMT(th1) t_hand += th1 - th0; })
         }
@@ -419,17 +465,32 @@ __global__ __launch_bounds__(256) void slice_sm_kernel(UpdateDesc d, SliceSync* 
 }
 
 int update_sm_init_device() {
-    DQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(slice_sm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    DQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(slice_sm_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    DQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(slice_sm_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    DQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(slice_sm_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    DQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(slice_sm_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     return 0;
 }
 
-// the whole local update of time slice l in one launch (caller: launch_update_slice, which has checked n <= 256, GT valid, reservation held)
+// flush workgroups of the persistent slice kernels: one per 32 x 32 tile while there are at most 192 tiles, else every workgroup
+// owns ceil(tiles / 192) tiles (n = 576: 324 tiles, two per workgroup, 162 workgroups)
+int slice_flush_workgroups(int n) {
+    const int tiles = (n + 31) / 32, T = tiles * tiles;
+    if (T <= 192) return T;
+    const int per = (T + 191) / 192;
+    return (T + per - 1) / per;
+}
+
+// the whole local update of time slice l in one launch (caller: launch_update_slice, which has checked GT and the CU reservation)
 int launch_update_slice_sm(const UpdateDesc& d, int l, int acc_slot, int n_chains, hipStream_t s) {
     const int n = d.n;
-    if (n > 256 || !d.Cpanel || !d.slice_sync || !d.GT.p) { set_error("sub-matrix slice kernel: n <= 256, panel / sync / transposed workspaces required"); return -1; }
-    const int tiles = (n + 31) / 32;
-    hipLaunchKernelGGL(slice_sm_kernel, dim3(1 + tiles * tiles, n_chains), dim3(256), sm_lds_bytes(n), s, d, reinterpret_cast<SliceSync*>(d.slice_sync), l, acc_slot,
-                       tiles, d.info);
+    if (n > 1024 || !d.Cpanel || !d.slice_sync || !d.GT.p) { set_error("sub-matrix slice kernel: n <= 1024, panel / sync / transposed workspaces required"); return -1; }
+    const int tiles = (n + 31) / 32, kd = sm_pick_kd(n);
+    const dim3 grid(1 + slice_flush_workgroups(n), n_chains), block(256);
+    const size_t lds = sm_lds_bytes(n, kd);
+#define SM_LAUNCH(NS) hipLaunchKernelGGL((slice_sm_kernel<NS>), grid, block, lds, s, d, reinterpret_cast<SliceSync*>(d.slice_sync), l, acc_slot, tiles, kd, d.info)
+    if (n <= 256) SM_LAUNCH(1); else if (n <= 512) SM_LAUNCH(2); else if (n <= 768) SM_LAUNCH(3); else SM_LAUNCH(4);
+#undef SM_LAUNCH
     DQ_HIP(hipGetLastError());
     return 0;
 }

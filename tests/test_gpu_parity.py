@@ -632,3 +632,29 @@ def test_mid_sizes_between_the_named_configs(hip, orc, L1, L2):
     e.sweep_beta_to_0(*s2); o.sweep_beta_to_0(*s2)
     assert (e.get_fields() == o.get_fields()).all() and close(e.get_G(), o.get_G())
     assert e.stats().n_accepted == o.stats().n_accepted
+
+
+@pytest.mark.parametrize("L1,L2", [(20, 16), (24, 24), (32, 28)])
+def test_large_lattices_submatrix_walk_and_cooperative_qrcp(hip, orc, L1, L2):
+    """256 < N <= 1024 (N = 320, 576, 896: two, three and four site slots per thread): the persistent sub-matrix slice kernel
+    (update_sm.hip, windows of 31 / 15 / 8 flips, flush workgroups owning several tiles) and the cooperative QRCP (qr_coop.hip)
+    against the oracle (LAPACK back end when present, for speed): exact fields and accepted counts, G to 1e-10 * max|G| after each
+    half sweep, log det, wrap errors of the same size."""
+    m = HubbardModel(L1=L1, L2=L2, U=4.0, beta=1.0, nt=10, n_stab=5); f = m.random_fields(77)
+    fast = orc.set_backend("lapack")
+    try:
+        e = m.engine(hip); e.set_fields(f); e.init(); o = m.engine(orc); o.set_fields(f); o.init()
+        assert close(e.get_G(), o.get_G())
+        assert abs(e.get_logdet() - o.get_logdet()) < 1e-9 * max(1.0, abs(o.get_logdet()))
+        rng = np.random.default_rng(9)
+        s1, s2 = m.random_stream(rng), m.random_stream(rng)
+        e.sweep_0_to_beta(*s1); o.sweep_0_to_beta(*s1)
+        assert (e.get_fields() == o.get_fields()).all() and close(e.get_G(), o.get_G())
+        e.sweep_beta_to_0(*s2); o.sweep_beta_to_0(*s2)
+        assert (e.get_fields() == o.get_fields()).all() and close(e.get_G(), o.get_G())
+        se, so = e.stats(), o.stats()
+        print(f"N = {m.n}: acc {se.n_accepted}, max wrap err gpu {se.max_err:.2e} cpu {so.max_err:.2e}, lapack oracle = {fast}")
+        assert se.n_accepted == so.n_accepted and 0.2 < se.n_accepted / se.n_proposed < 0.9
+        assert se.max_err < 10 * max(so.max_err, 1e-12)
+    finally:
+        orc.set_backend("builtin")

@@ -63,9 +63,12 @@ def test_cfg4_replica_exchange_on_hip_engines(hip, orc):
             if rnd == 0:
                 assert res[0].partner == 7 and res[7].partner == 0 and res[0].decider == 1        # the wrap pair, rank 0 decides
         assert {True, False} <= {a for _, a in seen}, "both an accepted and a rejected swap must occur"
-        pt.sweeps(1, concurrently=True); tw.sweeps(1)          # 8 engines sweeping at once on one device
+        pt.sweeps(1, concurrently=os.environ.get("DQMC_TEST_PT_SEQUENTIAL") is None); tw.sweeps(1)          # 8 engines sweeping at once on one device
         for r in range(8):
             g, o = pt.get(r, n, nt), tw.get(r)
+            if not np.array_equal(g["fields"], o["fields"]):
+                bad = np.nonzero((g["fields"] != o["fields"]).any(axis=1))[0]
+                print(f"replica {r}: {len(bad)} slices differ, first {bad[:8]}, sites of the first: {np.nonzero(g['fields'][bad[0]] != o['fields'][bad[0]])[0][:8]}")
             assert np.array_equal(g["fields"], o["fields"]), r
             assert np.abs(g["G"] - o["G"]).max() <= TOL * max(1.0, np.abs(o["G"]).max())
         res, ref = pt.exchange(), tw.exchange()
