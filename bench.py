@@ -381,7 +381,7 @@ def main():
             out["replica_exchange"] = rex
         print(json.dumps(out), flush=True)
     if rex is not None and rex.get("hung"):
-        os._exit(0 if rank == 0 else 3)              # a communicator that never formed cannot be torn down either
+        sys.stdout.flush(); os._exit(0)              # a communicator that never formed cannot be torn down either; the JSON line carries the error
     eng.close()
     finalize(d)
 
