@@ -68,7 +68,9 @@ def test_cfg4_replica_exchange_on_hip_engines(hip, orc):
             g, o = pt.get(r, n, nt), tw.get(r)
             if not np.array_equal(g["fields"], o["fields"]):
                 bad = np.nonzero((g["fields"] != o["fields"]).any(axis=1))[0]
-                print(f"replica {r}: {len(bad)} slices differ, first {bad[:8]}, sites of the first: {np.nonzero(g['fields'][bad[0]] != o['fields'][bad[0]])[0][:8]}")
+                print(f"replica {r}: {int((g['fields'] != o['fields']).sum())} field entries in {len(bad)} slices differ, slices {bad[:12]}, sites of the first: "
+                      f"{np.nonzero(g['fields'][bad[0]] != o['fields'][bad[0]])[0][:12]}, gpu {g['fields'][bad[0]][:8]} cpu {o['fields'][bad[0]][:8]}, "
+                      f"max|dG| {np.abs(g['G'] - o['G']).max():.3e}, accepted gpu/cpu {g['accepted']}/{o['accepted']}")
             assert np.array_equal(g["fields"], o["fields"]), r
             assert np.abs(g["G"] - o["G"]).max() <= TOL * max(1.0, np.abs(o["G"]).max())
         res, ref = pt.exchange(), tw.exchange()
