@@ -140,6 +140,14 @@ def cpu_baseline(model, seed, budget_s=20.0, lib=None, device=0, config="cfg3"):
     return out
 
 
+def pmc_traffic(config, chains):
+    """Measured HBM bytes per launch of the dominant kernel (counter passes committed under profiles/), or None."""
+    path = os.path.join(ROOT, "profiles", "r02_pmc_slice_kernel.json")
+    if config != "cfg3" or chains != 1 or not os.path.exists(path):
+        return None
+    return float(json.load(open(path))["traffic_bytes_per_launch"])
+
+
 def spawn_ranks(n: int, argv, extra_env=None, timeout=None) -> int:
     """Start n fresh rank processes of this script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set) and wait for them;
     their stdout / stderr pass through.  Returns the largest exit code.  Called before the parent makes any GPU call."""
@@ -320,10 +328,10 @@ def main():
             "acceptance": acc_rate, "max_wrap_err": s1.max_err, "mean_wrap_err": s1.mean_err,
             "roofline": {"kernel": "local update of one time slice (slice_kernel: walk + flush roles)", "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         # HBM-side bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, KB;
-                         # one slice_kernel dispatch per slice -- the G -> GT copy comes out of the wrap GEMM's epilogue --, ~150 accepted
-                         # flips in the probed slices; profiles/r01_pmc_fetch_write_cfg3_4slices_v3_final.csv); cfg3, single-launch path only
-                         "traffic": (1024.0 * (2 * 4663.3 + 5747.4) * C) if (args.config == "cfg3" and C <= 3) else None,
+                         # HBM-side bytes per launch from rocprofv3 PMC passes of this round's binary on the same start state (FETCH_SIZE x2
+                         # gfx950 correction + WRITE_SIZE, separate passes; profiles/r02_pmc_slice_kernel.json names the CSVs and the command);
+                         # cfg3, single chain, single-launch path only
+                         "traffic": pmc_traffic(args.config, C),
                          "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_launch_s * 1e3,
                          "launches": upd_launches, "accepted": upd_acc,
                          "time_share_of_sweep": (upd_ms * 1e-3) / dt},

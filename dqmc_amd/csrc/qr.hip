@@ -298,8 +298,8 @@ __global__ __launch_bounds__(256) void formq_blocked_kernel(CMat Am, const doubl
     const int rg = lane & 15, cq = lane >> 4;
     const int c = blockIdx.x * 16 + wave * 4 + cq;             // my column (< n: n is a multiple of 16)
     const int cw_max = blockIdx.x * 16 + wave * 4 + 3;         // largest column of this wave
-    __shared__ int s_jpvt[256];
-    __shared__ double s_tau[256];
+    __shared__ int s_jpvt[16 * NRR];
+    __shared__ double s_tau[16 * NRR];
     for (int k = threadIdx.x; k < n; k += blockDim.x) { s_jpvt[k] = jpvt[k]; s_tau[k] = tau[k]; }
     __syncthreads();
     double q[NRR];
@@ -319,12 +319,12 @@ __global__ __launch_bounds__(256) void formq_blocked_kernel(CMat Am, const doubl
 
 static bool formq_blocked_ok(int n) {
     static const bool off = getenv("DQMC_FORMQ_CLASSIC") != nullptr;     // A/B switch
-    return !off && (n == 16 || n == 32 || n == 64 || n == 128 || n == 256);      // NRR = n / 16 exactly: no row bound checks in the kernel
+    return !off && (n == 16 || n == 32 || n == 64 || n == 128 || n == 256 || n == 576);      // NRR = n / 16 exactly: no row bound checks in the kernel
 }
 static void launch_formq_blocked(CMat A, const QrWork& w, Mat L, int n, int n_chains, hipStream_t s) {
     const dim3 grid(n / 16, n_chains), block(256);
 #define DQ_FQ(NRR) hipLaunchKernelGGL((formq_blocked_kernel<NRR>), grid, block, 0, s, A, (const double*)w.tau, w.tau_stride, (const int*)w.jpvt, w.jpvt_stride, L, n)
-    if (n <= 16) DQ_FQ(1); else if (n <= 32) DQ_FQ(2); else if (n <= 64) DQ_FQ(4); else if (n <= 128) DQ_FQ(8); else DQ_FQ(16);
+    if (n <= 16) DQ_FQ(1); else if (n <= 32) DQ_FQ(2); else if (n <= 64) DQ_FQ(4); else if (n <= 128) DQ_FQ(8); else if (n <= 256) DQ_FQ(16); else DQ_FQ(36);
 #undef DQ_FQ
 }
 

@@ -153,7 +153,8 @@ __global__ __launch_bounds__(QC_T) void qrcp_coop_kernel(Mat Am, QrWork w, int n
         }
         __syncthreads();
         // ---- [3] publish {norm, column, tau, beta, v} as tagged granules ----
-        for (int r = t; r < n; r += QC_T) {
+        const int r_lo = (i / QC_T) * QC_T;                  // v is zero above row i and nobody reads rows below block jb: skip whole chunks
+        for (int r = r_lo + t; r < n; r += QC_T) {
             double vmine = 0.0;
             if (have) { if (r == i) vmine = 1.0; else if (r > i) vmine = xbuf[r] * scal[2]; }
             put_f64(myrec, QC_HDR + r, vmine, tag);
@@ -199,7 +200,7 @@ __global__ __launch_bounds__(QC_T) void qrcp_coop_kernel(Mat Am, QrWork w, int n
             for (;;) {
                 bool ok = get_f64(wrec, 2, tag, tau_i);
                 ok = get_f64(wrec, 3, tag, beta) && ok;
-                for (int r = t; r < n; r += QC_T) { double vr; ok = get_f64(wrec, QC_HDR + r, tag, vr) && ok; vbuf[r] = vr; }
+                for (int r = r_lo + t; r < n; r += QC_T) { double vr; ok = get_f64(wrec, QC_HDR + r, tag, vr) && ok; vbuf[r] = vr; }
                 if (__all(ok)) break;
                 if (++spins > QC_SPIN_LIMIT || __hip_atomic_load(abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
                     __hip_atomic_store(abort_w, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -211,7 +212,7 @@ __global__ __launch_bounds__(QC_T) void qrcp_coop_kernel(Mat Am, QrWork w, int n
         }
         // ---- [5] the winner records the reflector, tau, jpvt ----
         if (wwin == wg) {
-            for (int r = t; r < n; r += QC_T) { if (r == i) A[r + (long)n * p] = beta; else if (r > i) A[r + (long)n * p] = vbuf[r]; }
+            for (int r = r_lo + t; r < n; r += QC_T) { if (r == i) A[r + (long)n * p] = beta; else if (r > i) A[r + (long)n * p] = vbuf[r]; }
             if (t == 0) { tau[i] = tau_i; jpvt[i] = p; pposl[p & 31] = i; }
             wlive &= ~(1u << (p & 31));
         }
