@@ -264,7 +264,7 @@ __device__ __forceinline__ double vec_get16(d16v v, int q) { return v[q]; }
 // that every set is addressed statically): while group g is walked, the G column / row elements of groups g + 1 and
 // g + 2 are in flight, and nothing but those loads is outstanding, so the wait before a group is a partial vmcnt.
 template <bool COH, bool PANELS = true>     // PANELS: write the window's U / W rows to memory for flush workgroups / kernels (the solo kernel flushes from LDS)
-__device__ __forceinline__ int walk_window(const ScanShared& sh, int& pos, double dg, int n, int kd, int j, bool live, const double* __restrict__ G,
+__device__ __forceinline__ int walk_window(const ScanShared& sh, int& pos, double& dg, int n, int kd, int j, bool live, const double* __restrict__ G,
                                            const double* __restrict__ GT, const UpdateDesc& d, long slice_off, int chain, int8_t* fields_g,
                                            double* __restrict__ Up, double* __restrict__ Wp PROF_ARG) {
     const int lane = threadIdx.x & 63, r16 = lane & 15, q8 = lane & 7;
@@ -459,7 +459,8 @@ __global__ __launch_bounds__(MAXT) void scan_kernel(UpdateDesc d, int l, int acc
 #endif
     if constexpr (REGS) {
         const double* __restrict__ GT = d.GT.at(chain);
-        k = walk_window<false>(sh, pos, live ? sh.diag[j] : 0.0, n, kd, j, live, G, GT, d, slice_off, chain, fields_g, Up, Wp PROF_PASS);
+        double dg0 = live ? sh.diag[j] : 0.0;
+        k = walk_window<false>(sh, pos, dg0, n, kd, j, live, G, GT, d, slice_off, chain, fields_g, Up, Wp PROF_PASS);
     } else {
         double pcA[SCAN_PF], prA[SCAN_PF], pcB[SCAN_PF], prB[SCAN_PF];
         int g = pos / SCAN_PF;
@@ -646,7 +647,10 @@ __global__ __launch_bounds__(256) void slice_kernel(UpdateDesc d, SliceSync* syn
                 if (broken && lane == 0) { __hip_atomic_store(&sy->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (info) atomicOr(info, 4); }
             }
             __syncthreads();
-            if (live) { dg = ld_coh(G + j + (long)n * j); sh.diag[j] = dg; }     // G changed: diagonal and prefetch restart from memory
+            // G changed: the prefetch restarts from memory.  The diagonal does not: the lane's running value dg (advanced by pu * wj at
+            // every accepted flip) IS G_jj after the flush up to the summation order, so the next window starts from it instead of
+            // paying an L2 round trip in front of the prefetch (it is re-read from G at the start of every slice)
+            if (live) sh.diag[j] = dg;
             __syncthreads();
 #ifdef DQ_SCAN_STAMPS
             { unsigned long long th1; STAMP(th1) t_hand += th1 - th0; }

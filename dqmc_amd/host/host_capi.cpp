@@ -232,6 +232,8 @@ int dqmc_host_pt_get(void* p, int rank, int64_t* fields, double* G, double* logd
         return 0;
     } catch (const std::exception& e) { if (err && errlen > 0) { std::strncpy(err, e.what(), errlen - 1); err[errlen - 1] = 0; } return -1; }
 }
+// DQMC::max_err() of one replica (the largest wrap-vs-stabilised difference since its engine was created)
+double dqmc_host_pt_max_err(void* p, int rank) { try { return static_cast<PtWorld*>(p)->reps.at(rank)->sim.max_err(); } catch (...) { return -1.0; } }
 // the raw generator of a replica: lets a test advance a twin utility::random in lock-step
 unsigned int dqmc_host_pt_rng_peek(void* p, int rank) { std::mt19937 g = static_cast<PtWorld*>(p)->reps.at(rank)->rng.get_generator(); return g(); }
 

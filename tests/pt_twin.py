@@ -41,6 +41,7 @@ def load_host():
     h.dqmc_host_pt_get.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 6 + [C.c_char_p, C.c_int]
     h.dqmc_host_pt_rng_peek.restype = C.c_uint; h.dqmc_host_pt_rng_peek.argtypes = [C.c_void_p, C.c_int]
     h.dqmc_host_hub_selftest.argtypes = [C.c_int, C.c_int]
+    h.dqmc_host_pt_max_err.restype = C.c_double; h.dqmc_host_pt_max_err.argtypes = [C.c_void_p, C.c_int]
     return h
 
 
@@ -87,6 +88,9 @@ class HostPT:
 
     def rng_peek(self, rank: int) -> int:
         return int(self.h.dqmc_host_pt_rng_peek(self.p, rank))
+
+    def max_err(self, rank: int) -> float:
+        return float(self.h.dqmc_host_pt_max_err(self.p, rank))
 
     def close(self):
         if self.p:
