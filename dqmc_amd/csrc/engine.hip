@@ -236,7 +236,7 @@ struct Engine {
     bool utTri[2] = {false, false}; bool ut_valid = false;
     double* utMeasNow = nullptr; double* utMeasSum = nullptr; long long ut_meas_count = 0;     // [C][3][nt + 1][n] dynamical observables: last / bin sums
     long long meas_count = 0;                                    // measurements accumulated in meas_sum
-    char* slice_sync = nullptr;                                  // [C][64 B] hand-off words of the persistent slice kernel
+    char* slice_sync = nullptr;                                  // [C][1 KiB] hand-off words of the persistent slice kernels
     bool persistent = false;                                     // holds a CU reservation for the single-launch slice kernel (slice_reserve)
     int* acc = nullptr;                                          // [C][nt]
     double* err = nullptr;                                       // [C][n_stack]
@@ -291,7 +291,7 @@ struct Engine {
         DQ_TRY(dalloc(&logdet, C));
         DQ_TRY(dalloc(&rs_perm, (size_t)C * nt * n)); DQ_TRY(dalloc(&rs_k, (size_t)C * nt * n)); DQ_TRY(dalloc(&rs_u, (size_t)C * nt * n));
         DQ_TRY(dalloc(&Upanel, (size_t)C * UPDATE_KD * n)); DQ_TRY(dalloc(&Wpanel, (size_t)C * UPDATE_KD * n)); DQ_TRY(dalloc(&Cpanel, (size_t)C * UPDATE_KD * UPDATE_KD));
-        DQ_TRY(dalloc(&state, (size_t)C * 4)); DQ_TRY(dalloc(&prep, (size_t)C * 4 * n)); DQ_TRY(dalloc(&meas_now, (size_t)C * (3 + n))); DQ_TRY(dalloc(&meas_sum, (size_t)C * (3 + n))); DQ_HIP(hipMemsetAsync(meas_sum, 0, sizeof(double) * C * (3 + n), s)); DQ_TRY(dalloc(&slice_sync, (size_t)C * 64)); DQ_HIP(hipMemsetAsync(slice_sync, 0, (size_t)C * 64, s)); DQ_TRY(dalloc(&acc, (size_t)C * nt)); DQ_TRY(dalloc(&err, (size_t)C * n_stack));
+        DQ_TRY(dalloc(&state, (size_t)C * 4)); DQ_TRY(dalloc(&prep, (size_t)C * 4 * n)); DQ_TRY(dalloc(&meas_now, (size_t)C * (3 + n))); DQ_TRY(dalloc(&meas_sum, (size_t)C * (3 + n))); DQ_HIP(hipMemsetAsync(meas_sum, 0, sizeof(double) * C * (3 + n), s)); DQ_TRY(dalloc(&slice_sync, (size_t)C * 1024)); DQ_HIP(hipMemsetAsync(slice_sync, 0, (size_t)C * 1024, s)); DQ_TRY(dalloc(&acc, (size_t)C * nt)); DQ_TRY(dalloc(&err, (size_t)C * n_stack));
         DQ_TRY(dalloc(&dstats, C)); DQ_TRY(dalloc(&r1scratch, (size_t)C * (2 * n + 1)));
         h_stage_bytes = (size_t)C * nt * n * (sizeof(int32_t) + sizeof(uint8_t) + sizeof(double));
         DQ_HIP(hipHostMalloc(&h_stage, h_stage_bytes, hipHostMallocDefault));
@@ -496,7 +496,7 @@ struct Engine {
         }
         int h_info = 0;
         DQ_HIP(hipMemcpy(&h_info, ctx.info(), sizeof(int), hipMemcpyDeviceToHost));
-        if (h_info & 4) { set_error("persistent slice kernel: a hand-off timed out (workgroups not co-resident?)"); (void)hipMemset(ctx.info(), 0, sizeof(int)); (void)hipMemset(slice_sync, 0, (size_t)C * 64); return DQMC_ENUMERIC; }
+        if (h_info & 4) { set_error("persistent slice kernel: a hand-off timed out (workgroups not co-resident?)"); (void)hipMemset(ctx.info(), 0, sizeof(int)); (void)hipMemset(slice_sync, 0, (size_t)C * 1024); return DQMC_ENUMERIC; }
         if (h_info & 2) { set_error("cooperative QRCP gave up waiting for a partner workgroup (not co-resident?)"); (void)hipMemset(ctx.info(), 0, sizeof(int)); return DQMC_ENUMERIC; }
         if (h_info) { set_error("LU factorisation hit a zero or NaN pivot"); (void)hipMemset(ctx.info(), 0, sizeof(int)); return DQMC_ENUMERIC; }
         return 0;

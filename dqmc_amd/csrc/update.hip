@@ -551,17 +551,20 @@ __global__ __launch_bounds__(256) void flush_kernel(UpdateDesc d, int tiles_per_
 // correction to it.  Replaces ceil(n/KD) x (scan launch + flush launch) per slice: per window the cost of two kernel
 // boundaries, a cold prologue and an empty-launch tail becomes one publish / arrive hand-off.
 //
-// Hand-off (cdna_hip_programming.md Guideline 16; placement-independent, every shared word an agent-scope access):
+// Hand-off (cdna_hip_programming.md Guideline 16; placement-independent, every shared word an agent-scope access; ONE wave per
+// workgroup polls, arrivals are per-workgroup words read by the walk with one coalesced load -- no read-modify-write on the path):
 //   walk  -> flush : when a window closes the panel rows are written with sc1 stores, every wave drains
 //                    (s_waitcnt vmcnt(0)), the workgroup barriers, one lane stores the granule
 //                    {tag = window number, value = k | final << 31}.  Flush workgroups poll that ONE word.
-//   flush -> walk  : tiles are read and written with sc1 accesses; each flush wave drains, barrier, one lane adds 1 to
-//                    the arrival counter; the walk polls the counter for F * window, then re-reads the diagonal and
-//                    restarts its prefetch with sc1 loads (no L1 copy of G is ever trusted).
+//   flush -> walk  : tiles are read and written with sc1 accesses; each flush wave drains, barrier, one lane stores the window
+//                    number into the workgroup's arrival word; the walk polls the F words (lane f <-> word f) until all carry the
+//                    window number, then restarts its prefetch with sc1 loads (no L1 copy of G is ever trusted; the diagonal
+//                    continues from the lane's running value).
 //   The words are zeroed by the LAST workgroup to leave (exit ticket), ready for the next launch; spins are bounded.
 // Needs all 1 + F workgroups of a chain co-resident (the walk's LDS allows one workgroup per CU), so the launcher only
 // takes this path while (1 + F) * chains fits the CU count, and falls back to the multi-kernel path otherwise.
-struct SliceSync { unsigned long long seq; unsigned int arrived; unsigned int exits; unsigned int error; unsigned int pad[11]; };   // 64 B per chain
+struct SliceSync { unsigned long long seq; unsigned int arrived; unsigned int exits; unsigned int error; unsigned int pad[11];   // 64 B
+                   unsigned int arrive[240]; };  // + one arrival word per flush workgroup (the first 64 are used here); 1 KiB per chain
 constexpr unsigned SLICE_SPIN_LIMIT = 1u << 20;
 
 __global__ __launch_bounds__(256) void slice_kernel(UpdateDesc d, SliceSync* sync_p, int l, int acc_slot, int kd, int tiles_per_dim, int* info) {
@@ -581,22 +584,32 @@ __global__ __launch_bounds__(256) void slice_kernel(UpdateDesc d, SliceSync* syn
         const int tile = blockIdx.x - 1;
         const int a0 = (tile % tiles_per_dim) * 32 + (wave & 1) * 16;
         const int b0 = (tile / tiles_per_dim) * 32 + (wave >> 1) * 16;
+        // one wave polls the window word (64 workgroups x 4 waves polling one L2 line slow the walk's own loads: guide, Pitfall 9),
+        // the others wait at the barrier and take the word from LDS
+        unsigned long long* bcast = reinterpret_cast<unsigned long long*>(smem);
         for (unsigned win = 1;; ++win) {
-            unsigned long long word = 0; unsigned spins = 0; bool give_up = false;
-            for (;;) {
-                word = __hip_atomic_load(&sy->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((unsigned)(word >> 32) == win) break;
-                if (++spins > SLICE_SPIN_LIMIT) { give_up = true; break; }
-                __builtin_amdgcn_s_sleep(1);
+            if (wave == 0) {
+                unsigned long long word = 0; unsigned spins = 0; bool give_up = false;
+                for (;;) {
+                    word = __hip_atomic_load(&sy->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((unsigned)(word >> 32) == win) break;
+                    if (++spins > SLICE_SPIN_LIMIT) { give_up = true; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (give_up && lane == 0) { __hip_atomic_store(&sy->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (info) atomicOr(info, 4); }
+                if (lane == 0) bcast[win & 1] = give_up ? ~0ULL : word;
             }
-            if (give_up) { if (t == 0) { __hip_atomic_store(&sy->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (info) atomicOr(info, 4); } break; }
+            __syncthreads();
+            const unsigned long long word = bcast[win & 1];
+            if (word == ~0ULL) break;
             const int k = (int)(word & 0x7fffffffULL);
             const bool final = (word >> 31) & 1ULL;
             if (k > 0 && a0 < n && b0 < n) flush_tile<true, true>(G, GT, Up, Wp, a0, b0, n, k, kd, lane);
             if (final) break;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains before the arrival is signalled
             __syncthreads();
-            if (t == 0) __hip_atomic_fetch_add(&sy->arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // arrival: this workgroup's own word (no read-modify-write on a shared counter: 64 atomics on one word serialise in L2)
+            if (t == 0) __hip_atomic_store(&sy->arrive[tile], win, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     } else {
         // ================= walk role =================
@@ -640,7 +653,9 @@ __global__ __launch_bounds__(256) void slice_kernel(UpdateDesc d, SliceSync* syn
             // wait until every tile has absorbed this window, then refresh the diagonal from the flushed G
             if (wave == 0) {
                 unsigned spins = 0;
-                while (__hip_atomic_load(&sy->arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)F * win) {
+                for (;;) {                                            // lane f <-> flush workgroup f (F <= 64): one coalesced load per poll
+                    const unsigned a = lane < F ? __hip_atomic_load(&sy->arrive[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : win;
+                    if (__all(a == win)) break;
                     if (++spins > SLICE_SPIN_LIMIT) { broken = true; break; }
                     __builtin_amdgcn_s_sleep(1);
                 }
@@ -670,6 +685,7 @@ __global__ __launch_bounds__(256) void slice_kernel(UpdateDesc d, SliceSync* syn
         if (ticket == (unsigned)F) {
             __hip_atomic_store(&sy->seq, 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&sy->arrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int f = 0; f < 64; ++f) __hip_atomic_store(&sy->arrive[f], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&sy->exits, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }

@@ -354,7 +354,7 @@ __device__ __forceinline__ void sm_flush_tile(double* __restrict__ G, double* __
     }
 }
 
-struct SliceSync { unsigned long long seq; unsigned int arrived; unsigned int exits; unsigned int error; unsigned int pad[11]; };   // 64 B per chain (as update.hip)
+struct SliceSync { unsigned long long seq; unsigned int arrived; unsigned int exits; unsigned int error; unsigned int pad[11]; unsigned int arrive[240]; };   // 1 KiB per chain (layout of update.hip; this kernel uses the counter)
 
 }  // namespace
 
@@ -377,15 +377,23 @@ __global__ __launch_bounds__(256) void slice_sm_kernel(UpdateDesc d, SliceSync* 
 
     if (blockIdx.x > 0) {
         // ================= flush role: 32x32 tiles of G, one 16x16 sub-tile per wave =================
+        // one wave polls the window word, the others take it from LDS (polling cost: guide, Guideline 16 Pitfall 9)
+        unsigned long long* bcast = reinterpret_cast<unsigned long long*>(smem);
         for (unsigned win = 1;; ++win) {
-            unsigned long long word = 0; unsigned spins = 0; bool give_up = false;
-            for (;;) {
-                word = __hip_atomic_load(&sy->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((unsigned)(word >> 32) == win) break;
-                if (++spins > SM_SPIN_LIMIT) { give_up = true; break; }
-                __builtin_amdgcn_s_sleep(1);
+            if (wave == 0) {
+                unsigned long long w_ = 0; unsigned spins = 0; bool give_up = false;
+                for (;;) {
+                    w_ = __hip_atomic_load(&sy->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((unsigned)(w_ >> 32) == win) break;
+                    if (++spins > SM_SPIN_LIMIT) { give_up = true; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (give_up && lane == 0) { __hip_atomic_store(&sy->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (info) atomicOr(info, 4); }
+                if (lane == 0) bcast[win & 1] = give_up ? ~0ULL : w_;
             }
-            if (give_up) { if (t == 0) { __hip_atomic_store(&sy->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (info) atomicOr(info, 4); } break; }
+            __syncthreads();
+            const unsigned long long word = bcast[win & 1];
+            if (word == ~0ULL) break;
             const int k = (int)(word & 0x7fffffffULL);
             const bool final = (word >> 31) & 1ULL;
             if (k > 0) {
