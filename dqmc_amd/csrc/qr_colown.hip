@@ -146,7 +146,9 @@ __global__ __launch_bounds__(CO_T) __attribute__((amdgpu_num_vgpr(32))) void qrc
     double* tau = w.tau + (long)chain * w.tau_stride;
     int* jpvt = w.jpvt + (long)chain * w.jpvt_stride;
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), half = wave >> 2;     // wave-uniform: everything derived from them lives in SGPRs
-    const int cw = (wave & 3) * 64;              // first column of this wave
+    // first column of this wave.  The two owners of a column (one per half) sit on DIFFERENT SIMDs (wave w runs on SIMD w & 3): the
+    // publish of the pivot column is 48 single-lane ds_write_b128 per owner, and two waves of one SIMD issue them one after the other
+    const int cw = (((wave & 3) + half) & 3) * 64;
 #define CO_IDS const int lane = co_lane(), col = cw + lane, r16 = lane & 15, t = wave * 64 + lane; (void)t; (void)r16;
     const int rbase = 64 + 96 * half;            // first register row
     const int lbase = 32 * half;                 // first LDS row handled by this thread
