@@ -173,6 +173,9 @@ int slice_flush_workgroups(int n);        // flush workgroups per chain of the p
 // CU reservation for the persistent single-launch slice kernel (see update.hip); an engine that holds one passes slice_sync
 bool slice_reserve(int device, int n, int n_chains);
 void slice_release(int device, int n, int n_chains);
+void slice_engine_created(int device);
+void slice_engine_destroyed(int device);
+bool slice_persistent_allowed(int device);    // false while more than three engines of this process share the device
 // standalone Sherman-Morrison rank-1 update (source/model.cpp:124-138), whole-chip streaming kernel
 int launch_rank1(Mat G, int i, double delta, double* scratch /*2n+1 doubles per chain*/, long scratch_stride, int n, int n_chains, hipStream_t s);
 

@@ -207,6 +207,7 @@ struct Engine {
     long nn = 0;
     std::vector<int> loc_l_end;
     std::vector<double> g_host, gamma_host, eta_host;
+    std::vector<unsigned char> seen;                             // scratch of the random-stream validation
     Ctx ctx;
     hipStream_t s = nullptr;
 
@@ -238,6 +239,7 @@ struct Engine {
     long long meas_count = 0;                                    // measurements accumulated in meas_sum
     char* slice_sync = nullptr;                                  // [C][1 KiB] hand-off words of the persistent slice kernels
     bool persistent = false;                                     // holds a CU reservation for the single-launch slice kernel (slice_reserve)
+    bool counted = false;                                        // registered in the per-device engine count (slice_engine_created)
     int* acc = nullptr;                                          // [C][nt]
     double* err = nullptr;                                       // [C][n_stack]
     DevStats* dstats = nullptr;                                  // [C]
@@ -262,6 +264,7 @@ struct Engine {
     ~Engine() {
         if (s) (void)hipStreamSynchronize(s);
         if (persistent) slice_release(device, n, C);
+        if (counted) slice_engine_destroyed(device);
         for (auto& p : ev_pairs) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
         if (stage_free) (void)hipEventDestroy(stage_free);
         void* ptrs[] = {utMeasNow, utMeasSum, utG[0], utG[1], utG[2], utTmp, utErr, utL[0], utL[1], utD[0], utD[1], utR[0], utR[1], utP[0], utP[1], meas_now, meas_sum, GT, slice_sync, prep, stackP, expK, invexpK, fields, expv, invexpv, tabs, tab8, G, Gtmp, bb0, bb1, stackL, stackD, stackR, tmpL, tmpD, tmpR,
@@ -281,6 +284,7 @@ struct Engine {
         g_host.assign(g, g + C); gamma_host.assign(gamma, gamma + 4); eta_host.assign(eta, eta + 4);
         DQ_TRY(ctx.init(n, C, device)); s = ctx.stream;
         persistent = slice_reserve(device, n, C);
+        slice_engine_created(device); counted = true;
         DQ_TRY(dalloc(&expK, C * nn)); DQ_TRY(dalloc(&invexpK, C * nn));
         DQ_TRY(dalloc(&fields, (size_t)C * nt * n)); DQ_TRY(dalloc(&expv, (size_t)C * nt * n)); DQ_TRY(dalloc(&invexpv, (size_t)C * nt * n));
         DQ_TRY(dalloc(&tabs, C)); DQ_TRY(dalloc(&tab8, (size_t)C * 8));
@@ -363,11 +367,11 @@ struct Engine {
         return ctx.gemm(ctx.T(0), CMat(expK, nn), mG(), CVec(), ev(l), CVec(), 0, 0, use_gt() ? Mat{GT, nn} : Mat{nullptr, 0});
     }
     // the walk reads rows of G from a transposed copy: the register walk (n <= 256) and the persistent sub-matrix kernel (any n)
-    bool use_gt() const { return n <= 256 || persistent; }
+    bool use_gt() const { return n <= 256 || persistent; }       // (kept in step even while the persistent kernel is not being launched)
     UpdateDesc udesc() const {
         UpdateDesc d; d.G = mG(); d.fields = fields; d.f_stride = (long)nt * n; d.expv = expv; d.invexpv = invexpv; d.v_stride = (long)nt * n;
         d.tabs = tabs; d.perm = rs_perm; d.kprop = rs_k; d.u = rs_u; d.rs_stride = (long)nt * n; d.Upanel = Upanel; d.Wpanel = Wpanel; d.Cpanel = Cpanel;
-        d.panel_stride = (long)UPDATE_KD * n; d.state = state; d.state_stride = 4; d.prep = prep; d.prep_stride = 4L * n; d.slice_sync = persistent ? slice_sync : nullptr; d.GT = Mat{GT, nn}; d.gt_valid = gt_valid ? 1 : 0; d.info = ctx.info(); d.acc_out = acc; d.acc_stride = nt; d.n = n; d.nt = nt;
+        d.panel_stride = (long)UPDATE_KD * n; d.state = state; d.state_stride = 4; d.prep = prep; d.prep_stride = 4L * n; d.slice_sync = (persistent && slice_persistent_allowed(device)) ? slice_sync : nullptr; d.GT = Mat{GT, nn}; d.gt_valid = gt_valid ? 1 : 0; d.info = ctx.info(); d.acc_out = acc; d.acc_stride = nt; d.n = n; d.nt = nt;
         return d;
     }
     int local_update(int l) {
@@ -383,6 +387,19 @@ struct Engine {
     }
     int upload_stream(const int32_t* perm, const uint8_t* kprop, const double* u) {
         const size_t cnt = (size_t)C * nt * n;
+        if (!perm || !kprop || !u) { set_error("sweep: null random-stream pointer"); return DQMC_EINVAL; }
+        // the device indexes G with perm and the proposal table with kprop: every slice must carry a permutation of the sites and
+        // proposal indices in {0, 1, 2} (what std::shuffle and uniform_int(0, 2) produce, source/update.cpp:14, include/field.h:79)
+        seen.assign((size_t)n, 0);
+        for (size_t row = 0; row < (size_t)C * nt; ++row) {
+            const int32_t* pr = perm + row * n; const uint8_t* kr = kprop + row * n; const unsigned char mark = (unsigned char)(1 + (row & 1));
+            if ((row & 1) == 0) std::fill(seen.begin(), seen.end(), 0);
+            for (int idx = 0; idx < n; ++idx) {
+                const int32_t i = pr[idx];
+                if (i < 0 || i >= n || seen[i] == mark || kr[idx] > 2) { set_error("sweep: perm is not a permutation of the sites, or kprop > 2"); return DQMC_EINVAL; }
+                seen[i] = mark;
+            }
+        }
         DQ_HIP(hipEventSynchronize(stage_free));                   // previous H2D copies out of the staging buffer are done
         char* base = static_cast<char*>(h_stage);
         double* hu = reinterpret_cast<double*>(base);
@@ -750,6 +767,15 @@ int dqmc_wrap_backward(dqmc_engine* h, int l) {
 int dqmc_local_update_slice(dqmc_engine* h, int l, const int32_t* perm, const uint8_t* kprop, const double* u, int* accepted) {
     CHECK_E(h); Engine& e = h->e; DQ_HIP(hipSetDevice(e.device));
     if (l < 0 || l >= e.nt) { set_error("time slice out of range"); return DQMC_ERANGE; }
+    if (!perm || !kprop || !u) { set_error("local_update_slice: null random-stream pointer"); return DQMC_EINVAL; }
+    for (int c = 0; c < e.C; ++c) {                                          // same contract as the sweeps (Engine::upload_stream)
+        std::vector<unsigned char> seen((size_t)e.n, 0);
+        for (int idx = 0; idx < e.n; ++idx) {
+            const int32_t i = perm[(size_t)c * e.n + idx];
+            if (i < 0 || i >= e.n || seen[i] || kprop[(size_t)c * e.n + idx] > 2) { set_error("local_update_slice: perm is not a permutation of the sites, or kprop > 2"); return DQMC_EINVAL; }
+            seen[i] = 1;
+        }
+    }
     DQ_HIP(hipStreamSynchronize(e.s));
     for (int c = 0; c < e.C; ++c) {
         const size_t off = ((size_t)c * e.nt + l) * e.n;

@@ -19,6 +19,7 @@
 //   scan_kernel<1024> + n > 256: the pending pairs live in LDS (scan_group), G rows are read directly (no GT).
 //   flush_kernel<false>
 #include "common.h"
+#include <atomic>
 #include <cstdlib>
 #include <mutex>
 #include "wave.h"
@@ -816,6 +817,7 @@ static int pick_kd(int n) {
 static std::mutex g_resv_mu;
 static int g_resv_used[64] = {};
 static int g_resv_cap[64] = {};
+static std::atomic<int> g_engines[64];         // engines alive per device (this process)
 int slice_workgroups(int n, int n_chains) { return (1 + slice_flush_workgroups(n)) * n_chains; }
 bool slice_reserve(int device, int n, int n_chains) {
     if (device < 0 || device >= 64 || n > 1024) return false;
@@ -830,6 +832,17 @@ bool slice_reserve(int device, int n, int n_chains) {
     if (g_resv_used[device] + want > g_resv_cap[device]) return false;
     g_resv_used[device] += want;
     return true;
+}
+// Engines of this process on the device.  The persistent kernels are only launched while there are at most three: with 8 or 16
+// single-chain engines of one process sweeping at once on one device (4 HW queues shared by all their streams, CUs oversubscribed)
+// a transient G error inside one stabilisation block was observed on engines running the persistent kernel about once per 650
+// engine-sweeps (never on the engines on kernel pairs: 0 in 8 450; never with <= 6 engines: 0 in 2 300; scripts/pt_stress.py).
+// Many chains per device belong in ONE batched engine (dqmc_create_batch) anyway.
+void slice_engine_created(int device) { if (device >= 0 && device < 64) g_engines[device].fetch_add(1); }
+void slice_engine_destroyed(int device) { if (device >= 0 && device < 64) g_engines[device].fetch_sub(1); }
+bool slice_persistent_allowed(int device) {
+    static const int max_engines = getenv("DQMC_SLICE_MAX_ENGINES") ? atoi(getenv("DQMC_SLICE_MAX_ENGINES")) : 3;
+    return device >= 0 && device < 64 && g_engines[device].load() <= max_engines;
 }
 void slice_release(int device, int n, int n_chains) {
     if (device < 0 || device >= 64) return;

@@ -553,6 +553,21 @@ def test_error_codes(hip):
     bad = m.random_fields(1); bad[0, 0] = 7
     with pytest.raises(DqmcError):
         e.set_fields(bad)
+    # the random stream is validated on the host before it reaches a kernel: perm must be a permutation per slice, kprop in {0, 1, 2}
+    perm, k, u = m.random_stream(np.random.default_rng(0))
+    p2 = perm.copy(); p2[3, 5] = p2[3, 6]
+    with pytest.raises(DqmcError) as ei:
+        e.sweep_0_to_beta(p2, k, u)
+    assert ei.value.code == -1
+    p3 = perm.copy(); p3[0, 0] = m.n
+    with pytest.raises(DqmcError):
+        e.sweep_beta_to_0(p3, k, u)
+    k2 = k.copy(); k2[7, 1] = 3
+    with pytest.raises(DqmcError):
+        e.sweep_0_to_beta(perm, k2, u)
+    with pytest.raises(DqmcError):
+        e.local_update_slice(0, p2[3], k[3], u[3])
+    e.sweep_0_to_beta(perm, k, u); e.sync()                    # the engine is still usable
 
 
 @pytest.mark.parametrize("name", golden_util.NAMES)

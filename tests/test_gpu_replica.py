@@ -84,13 +84,10 @@ def test_cfg4_replica_exchange_on_hip_engines(hip, orc):
 
 
 def test_many_engines_sweeping_at_once_on_one_device(hip):
-    """8 single-chain engines (cfg-4 size) driven by 8 host threads on ONE device, two sweeps each: the first three hold CU
-    reservations for the persistent slice kernel, the others take the scan / flush kernel pairs (slice_reserve, update.hip).  No
-    hand-off may time out (a time-out is an error return), and every engine must end self-consistent: its G equals the
-    from-scratch evaluation of its own final fields.  Trajectories are NOT compared here: with 16 engines of one process
-    oversubscribing the device a transient G error inside one stabilisation block (healed by the next stabilisation, visible as a
-    wrap error of O(1)) was observed about once per thousand engine-sweeps (scripts/pt_stress.py; never with up to 6 engines, never
-    with one engine per device), see DESIGN.md section 7."""
+    """8 single-chain engines (cfg-4 size) driven by 8 host threads on ONE device, two sweeps each.  With more than three engines
+    of one process on a device every engine takes the scan / flush kernel pairs (slice_persistent_allowed, update.hip; DESIGN.md
+    section 7 has the stress measurements behind that rule).  No hand-off may time out (a time-out is an error return), and every
+    engine must end self-consistent: its G equals the from-scratch evaluation of its own final fields."""
     cfg = CONFIGS["cfg4"]; L, U, nt, n_stab = cfg["L1"], cfg["U"], cfg["nt"], cfg["n_stab"]; n = L * L
     betas = [8.0 - 0.5 * r for r in range(8)]; seeds = [500 + r for r in range(8)]
     h = load_host()
