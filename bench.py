@@ -326,7 +326,8 @@ def main():
                        "chains_per_gpu": C, "n_chains_total": world * C, "parallelism": f"independent chains, {world} gpu x {C} chain"},
             "start": start,
             "acceptance": acc_rate, "max_wrap_err": s1.max_err, "mean_wrap_err": s1.mean_err,
-            "roofline": {"kernel": "local update of one time slice (slice_kernel: walk + flush roles)", "bound": "hbm",
+            "roofline": {"kernel": "local update of one time slice (" + ("slice_kernel: delayed-update walk + flush roles" if n <= 256 else
+                                                                         "slice_sm_kernel: sub-matrix walk + flush roles") + ")", "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          # HBM-side bytes per launch from rocprofv3 PMC passes of this round's binary on the same start state (FETCH_SIZE x2
                          # gfx950 correction + WRITE_SIZE, separate passes; profiles/r02_pmc_slice_kernel.json names the CSVs and the command);

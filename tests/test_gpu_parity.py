@@ -649,13 +649,14 @@ def test_mid_sizes_between_the_named_configs(hip, orc, L1, L2):
     assert e.stats().n_accepted == o.stats().n_accepted
 
 
-@pytest.mark.parametrize("L1,L2", [(20, 16), (24, 24), (32, 28)])
+@pytest.mark.parametrize("L1,L2", [(20, 16), (17, 17), (24, 24), (25, 21), (32, 28)])
 def test_large_lattices_submatrix_walk_and_cooperative_qrcp(hip, orc, L1, L2):
-    """256 < N <= 1024 (N = 320, 576, 896: two, three and four site slots per thread): the persistent sub-matrix slice kernel
+    """256 < N <= 1024 (N = 320, 289, 576, 525, 896: two, three and four site slots per thread; 289 and 525 are multiples of neither
+    16 nor 32: partial MFMA tiles in the flushes, padding rows and a short last workgroup in the QRCP): the persistent sub-matrix slice kernel
     (update_sm.hip, windows of 31 / 15 / 8 flips, flush workgroups owning several tiles) and the cooperative QRCP (qr_coop.hip)
     against the oracle (LAPACK back end when present, for speed): exact fields and accepted counts, G to 1e-10 * max|G| after each
     half sweep, log det, wrap errors of the same size."""
-    m = HubbardModel(L1=L1, L2=L2, U=4.0, beta=1.0, nt=10, n_stab=5); f = m.random_fields(77)
+    m = HubbardModel(L1=L1, L2=L2, U=4.0, beta=1.0, nt=12 if L1 == 17 else 10, n_stab=5); f = m.random_fields(77)   # nt = 12: a short last block too
     fast = orc.set_backend("lapack")
     try:
         e = m.engine(hip); e.set_fields(f); e.init(); o = m.engine(orc); o.set_fields(f); o.init()
