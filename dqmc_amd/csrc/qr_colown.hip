@@ -21,9 +21,8 @@
 //   * barriers order LDS only (s_waitcnt lgkmcnt(0) + s_barrier): the reflector / tau / jpvt stores to HBM are
 //     fire-and-forget.
 // Thread map (512 threads = 8 waves, two per SIMD): col = t & 255, half = t >> 8.
-//   half 0: LDS rows 0..31   + register rows  64..159      half 1: LDS rows 32..63 + register rows 160..255
-// The half that owns row k ("active" half of step k) carries the partial column norms vn1 / vn2; they are handed
-// over through LDS at k = 32, 64, 160.
+//   half h: the 16-row blocks h, h + 2 in LDS and 4 + h, 6 + h, ..., 14 + h in registers (interleaved: see CO_ACT)
+// The half that owns row k ("active" half of step k) updates the partial column norms vn1 / vn2, which live in LDS.
 // Register file by hand.  192 of the 256 VGPRs of a thread hold matrix rows for the whole kernel, and the register
 // allocator cannot be talked into that: as C arrays or vector types the rows were spilled and reloaded around every
 // asm block (2755 .. 10139 spills, 2.7 ms per factorisation).  So the matrix registers are taken out of its hands:
@@ -118,8 +117,11 @@ struct CoShared {
 
 }  // namespace
 
-// which half owns row k of row block JB: LDS blocks 0,1 -> half 0; 2,3 -> half 1; register blocks 4..9 -> half 0; 10..15 -> half 1
-#define CO_ACT(JB) ((JB) < 2 ? 0 : (JB) < 4 ? 1 : (JB) < 10 ? 0 : 1)
+// which half owns row k of row block JB: even blocks -> half 0, odd blocks -> half 1, in LDS (blocks 0..3) and in registers (4..15)
+// alike.  Row k is final after step k, so a half loses a 16-row block every 32 steps: with the blocks INTERLEAVED both halves
+// shrink at the same rate and the dots / update phases of the two waves of a SIMD stay balanced (contiguous halves left the
+// first half idle ~1 000 clk per step waiting for the second at the end-of-step barrier).
+#define CO_ACT(JB) ((JB) & 1)
 
 __global__ __launch_bounds__(CO_T) __attribute__((amdgpu_num_vgpr(32))) void qrcp_colown_kernel(Mat Am, QrWork w, int n) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -150,8 +152,6 @@ __global__ __launch_bounds__(CO_T) __attribute__((amdgpu_num_vgpr(32))) void qrc
     // publish of the pivot column is 48 single-lane ds_write_b128 per owner, and two waves of one SIMD issue them one after the other
     const int cw = (((wave & 3) + half) & 3) * 64;
 #define CO_IDS const int lane = co_lane(), col = cw + lane, r16 = lane & 15, t = wave * 64 + lane; (void)t; (void)r16;
-    const int rbase = 64 + 96 * half;            // first register row
-    const int lbase = 32 * half;                 // first LDS row handled by this thread
     const double tol3z = 1.0536712127723509e-08; // sqrt(2^-53)
 
 
@@ -161,13 +161,13 @@ __global__ __launch_bounds__(CO_T) __attribute__((amdgpu_num_vgpr(32))) void qrc
         const bool live = col < n;                   // padding columns are never live
         if (half == 0) sh.livec[col] = live ? 1 : 0;
         double ssq = 0.0;
-#define CO_LOADV(C) ({ const int row = rbase + 16 * (C) + r; const double x = (row < n && col < n) ? A[row + (long)n * col] : 0.0; ssq += x * x; x; })
+#define CO_LOADV(C) ({ const int row = 16 * (4 + 2 * (C) + half) + r; const double x = (row < n && col < n) ? A[row + (long)n * col] : 0.0; ssq += x * x; x; })
         CO_RFOREACH_WR_0(CO_LOADV(0)) CO_RFOREACH_WR_1(CO_LOADV(1)) CO_RFOREACH_WR_2(CO_LOADV(2))
         CO_RFOREACH_WR_3(CO_LOADV(3)) CO_RFOREACH_WR_4(CO_LOADV(4)) CO_RFOREACH_WR_5(CO_LOADV(5))
 #undef CO_LOADV
 #pragma unroll 4
         for (int r = 0; r < 32; ++r) {
-            const int row = lbase + r;
+            const int row = 16 * (half + 2 * (r >> 4)) + (r & 15);            // LDS row blocks half, half + 2
             const double x = (row < n && col < n) ? A[row + (long)n * col] : 0.0;
             sh.alds[row * CO_N + col] = x; ssq += x * x;
         }
@@ -204,13 +204,14 @@ __global__ __launch_bounds__(CO_T) __attribute__((amdgpu_num_vgpr(32))) void qrc
     }
 #define CO_LDS_SCALE(GB) { _Pragma("unroll") for (int r = 0; r < 16; ++r) { if (16 * (GB) + r > k) sh.alds[(16 * (GB) + r) * CO_N + col] *= scale; } }
 #define CO_LDS_SUMSQ(GB) { _Pragma("unroll") for (int r = 0; r < 16; ++r) { const double x = (16 * (GB) + r > k) ? sh.alds[(16 * (GB) + r) * CO_N + col] : 0.0; psq += x * x; } }
-    // register block C of this half is global row block GB0 + C  (GB0 = 4 for half 0, 10 for half 1)
-#define CO_REG_X(C, GB0) const double x##C = ((GB0) + (C) >= (JB_)) ? CO_X((GB0) + (C)) : 0.0;
-#define CO_REG_DOT(C, GB0) if ((GB0) + (C) >= (JB_)) { CO_RDOT_##C(x##C) }
-#define CO_REG_AXPY(C, GB0) if ((GB0) + (C) >= (JB_)) { CO_RAXPY_##C(x##C, mw) }
-#define CO_REG_SCALE(C, GB0) if ((GB0) + (C) > (JB_)) CO_RFOREACH_MUL_##C(scale) else if ((GB0) + (C) == (JB_)) CO_RFOREACH_MUL_##C((16 * ((GB0) + (C)) + r > k) ? scale : 1.0)
-#define CO_REG_PUB(C, GB0) if ((GB0) + (C) >= (JB_)) { const unsigned a_ = vbuf_lds + 128u * ((GB0) + (C)); CO_RPUB_##C(a_) }
-#define CO_REG_SUMSQ(C, GB0) if ((GB0) + (C) >= (JB_)) CO_RFOREACH_RD_##C({ const double x = (16 * ((GB0) + (C)) + r > k) ? v : 0.0; psq += x * x; })
+    // register block C of a half is global row block 4 + 2 C (half 0, tag GB0 = 4) or 5 + 2 C (half 1, tag GB0 = 10)
+#define CO_GB(GB0, C) ((GB0) == 4 ? 4 + 2 * (C) : 5 + 2 * (C))
+#define CO_REG_X(C, GB0) const double x##C = (CO_GB(GB0, C) >= (JB_)) ? CO_X(CO_GB(GB0, C)) : 0.0;
+#define CO_REG_DOT(C, GB0) if (CO_GB(GB0, C) >= (JB_)) { CO_RDOT_##C(x##C) }
+#define CO_REG_AXPY(C, GB0) if (CO_GB(GB0, C) >= (JB_)) { CO_RAXPY_##C(x##C, mw) }
+#define CO_REG_SCALE(C, GB0) if (CO_GB(GB0, C) > (JB_)) CO_RFOREACH_MUL_##C(scale) else if (CO_GB(GB0, C) == (JB_)) CO_RFOREACH_MUL_##C((16 * (CO_GB(GB0, C)) + r > k) ? scale : 1.0)
+#define CO_REG_PUB(C, GB0) if (CO_GB(GB0, C) >= (JB_)) { const unsigned a_ = vbuf_lds + 128u * (CO_GB(GB0, C)); CO_RPUB_##C(a_) }
+#define CO_REG_SUMSQ(C, GB0) if (CO_GB(GB0, C) >= (JB_)) CO_RFOREACH_RD_##C({ const double x = (16 * (CO_GB(GB0, C)) + r > k) ? v : 0.0; psq += x * x; })
 #define CO_REG_ALL(OP, GB0) OP(0, GB0) OP(1, GB0) OP(2, GB0) OP(3, GB0) OP(4, GB0) OP(5, GB0)
 
     // ---- the steps of row block JB (k = 16 JB .. 16 JB + 15): blocks below JB are dead and not compiled in ----
@@ -241,11 +242,11 @@ __global__ __launch_bounds__(CO_T) __attribute__((amdgpu_num_vgpr(32))) void qrc
             if (half == 0) {                                                                                                          \
                 CO_REG_ALL(CO_REG_X, 4)                    /* all x loads of the phase in flight before the first FMA block */        \
                 CO_REG_ALL(CO_REG_DOT, 4)                                                                                             \
-                if (0 >= (JB)) CO_LDS_DOT(0) if (1 >= (JB)) CO_LDS_DOT(1)                                                             \
+                if (0 >= (JB)) CO_LDS_DOT(0) if (2 >= (JB)) CO_LDS_DOT(2)                                                             \
             } else {                                                                                                                  \
                 CO_REG_ALL(CO_REG_X, 10)                                                                                              \
                 CO_REG_ALL(CO_REG_DOT, 10)                                                                                            \
-                if (2 >= (JB)) CO_LDS_DOT(2) if (3 >= (JB)) CO_LDS_DOT(3)                                                             \
+                if (1 >= (JB)) CO_LDS_DOT(1) if (3 >= (JB)) CO_LDS_DOT(3)                                                             \
             }                                                                                                                         \
             sh.pdot[half * CO_N + col] = (d0 + d1) + (d2 + d3);                                                                       \
             if (half == act) {                                                                                                        \
@@ -253,9 +254,9 @@ __global__ __launch_bounds__(CO_T) __attribute__((amdgpu_num_vgpr(32))) void qrc
                 if ((JB) < 4) ak = sh.alds[k * CO_N + col];                                                                           \
                 else {                                                                                                                \
                     const int q = __builtin_amdgcn_readfirstlane(k & 15);                                                             \
-                    if (((JB) + 2) % 6 == 0) { CO_RGET_0(q, ak) } else if (((JB) + 2) % 6 == 1) { CO_RGET_1(q, ak) }                  \
-                    else if (((JB) + 2) % 6 == 2) { CO_RGET_2(q, ak) } else if (((JB) + 2) % 6 == 3) { CO_RGET_3(q, ak) }             \
-                    else if (((JB) + 2) % 6 == 4) { CO_RGET_4(q, ak) } else { CO_RGET_5(q, ak) }                                      \
+                    if ((((JB) - 4) >> 1) == 0) { CO_RGET_0(q, ak) } else if ((((JB) - 4) >> 1) == 1) { CO_RGET_1(q, ak) }                  \
+                    else if ((((JB) - 4) >> 1) == 2) { CO_RGET_2(q, ak) } else if ((((JB) - 4) >> 1) == 3) { CO_RGET_3(q, ak) }             \
+                    else if ((((JB) - 4) >> 1) == 4) { CO_RGET_4(q, ak) } else { CO_RGET_5(q, ak) }                                      \
                 }                                                                                                                     \
                 sh.rowk[col] = ak;                                                                                                    \
             }                                                                                                                         \
@@ -290,9 +291,9 @@ __global__ __launch_bounds__(CO_T) __attribute__((amdgpu_num_vgpr(32))) void qrc
                     if ((JB) < 4) sh.alds[k * CO_N + col] = rk;                                                                       \
                     else {                                                                                                            \
                         const int q = __builtin_amdgcn_readfirstlane(k & 15);                                                         \
-                        if (((JB) + 2) % 6 == 0) { CO_RSET_0(q, rk) } else if (((JB) + 2) % 6 == 1) { CO_RSET_1(q, rk) }              \
-                        else if (((JB) + 2) % 6 == 2) { CO_RSET_2(q, rk) } else if (((JB) + 2) % 6 == 3) { CO_RSET_3(q, rk) }         \
-                        else if (((JB) + 2) % 6 == 4) { CO_RSET_4(q, rk) } else { CO_RSET_5(q, rk) }                                  \
+                        if ((((JB) - 4) >> 1) == 0) { CO_RSET_0(q, rk) } else if ((((JB) - 4) >> 1) == 1) { CO_RSET_1(q, rk) }              \
+                        else if ((((JB) - 4) >> 1) == 2) { CO_RSET_2(q, rk) } else if ((((JB) - 4) >> 1) == 3) { CO_RSET_3(q, rk) }         \
+                        else if ((((JB) - 4) >> 1) == 4) { CO_RSET_4(q, rk) } else { CO_RSET_5(q, rk) }                                  \
                     }                                                                                                                 \
                 }                                                                                                                     \
                 double vn1 = sh.vn[col];                                                                                              \
@@ -311,12 +312,12 @@ __global__ __launch_bounds__(CO_T) __attribute__((amdgpu_num_vgpr(32))) void qrc
             if (half == 0) {                                                                                                          \
                 CO_REG_ALL(CO_REG_X, 4)                                                                                               \
                 CO_REG_ALL(CO_REG_AXPY, 4)                                                                                            \
-                if (0 >= (JB)) CO_LDS_AXPY(0) if (1 >= (JB)) CO_LDS_AXPY(1)                                                           \
+                if (0 >= (JB)) CO_LDS_AXPY(0) if (2 >= (JB)) CO_LDS_AXPY(2)                                                           \
                                                                       \
             } else {                                                                                                                  \
                 CO_REG_ALL(CO_REG_X, 10)                                                                                              \
                 CO_REG_ALL(CO_REG_AXPY, 10)                                                                                           \
-                if (2 >= (JB)) CO_LDS_AXPY(2) if (3 >= (JB)) CO_LDS_AXPY(3)                                                           \
+                if (1 >= (JB)) CO_LDS_AXPY(1) if (3 >= (JB)) CO_LDS_AXPY(3)                                                           \
                                                                      \
             }                                                                                                                         \
             /* the pivot column keeps x below row k; v = x * scale is formed when the matrix is written out (the scaling pass of   \
@@ -332,10 +333,10 @@ __global__ __launch_bounds__(CO_T) __attribute__((amdgpu_num_vgpr(32))) void qrc
                 double psq = 0.0;                                                                                                     \
                 if (mine) {                                                                                                           \
                     if (half == 0) {                                                                                                  \
-                        if (0 >= (JB)) CO_LDS_SUMSQ(0) if (1 >= (JB)) CO_LDS_SUMSQ(1)                                                 \
+                        if (0 >= (JB)) CO_LDS_SUMSQ(0) if (2 >= (JB)) CO_LDS_SUMSQ(2)                                                 \
                         CO_REG_ALL(CO_REG_SUMSQ, 4)                                                                                   \
                     } else {                                                                                                          \
-                        if (2 >= (JB)) CO_LDS_SUMSQ(2) if (3 >= (JB)) CO_LDS_SUMSQ(3)                                                 \
+                        if (1 >= (JB)) CO_LDS_SUMSQ(1) if (3 >= (JB)) CO_LDS_SUMSQ(3)                                                 \
                         CO_REG_ALL(CO_REG_SUMSQ, 10)                                                                                  \
                     }                                                                                                                 \
                 }                                                                                                                     \
@@ -374,13 +375,13 @@ __global__ __launch_bounds__(CO_T) __attribute__((amdgpu_num_vgpr(32))) void qrc
     if (col < n) {
         const int mypos = sh.posc[col];
         const double myscale = sh.vscale[col];
-#define CO_STOREV(C) { const int row = rbase + 16 * (C) + r; if (row < n) A[row + (long)n * col] = row > mypos ? v * myscale : v; }
+#define CO_STOREV(C) { const int row = 16 * (4 + 2 * (C) + half) + r; if (row < n) A[row + (long)n * col] = row > mypos ? v * myscale : v; }
         CO_RFOREACH_RD_0(CO_STOREV(0)) CO_RFOREACH_RD_1(CO_STOREV(1)) CO_RFOREACH_RD_2(CO_STOREV(2))
         CO_RFOREACH_RD_3(CO_STOREV(3)) CO_RFOREACH_RD_4(CO_STOREV(4)) CO_RFOREACH_RD_5(CO_STOREV(5))
 #undef CO_STOREV
 #pragma unroll 4
         for (int r = 0; r < 32; ++r) {
-            const int row = lbase + r;
+            const int row = 16 * (half + 2 * (r >> 4)) + (r & 15);
             if (row < n) { const double v = sh.alds[row * CO_N + col]; A[row + (long)n * col] = row > mypos ? v * myscale : v; }
         }
     }
