@@ -228,6 +228,7 @@ struct Engine {
     hipEvent_t stage_free = nullptr;
     double* Upanel = nullptr; double* Wpanel = nullptr;          // [C][KD][n]
     double* Cpanel = nullptr;                                    // [C][KD][KD]
+    double* ibuf = nullptr; int* ijp = nullptr;                  // batched initialisation (init_batched): Bbar ping-pong, L, R, d, tau / pivots of every block
     int* state = nullptr;                                        // [C][4]
     double* prep = nullptr;                                      // [C][4n]
     double* meas_now = nullptr; double* meas_sum = nullptr;      // [C][3 + n] equal-time observables: last evaluation / bin sums
@@ -268,7 +269,7 @@ struct Engine {
         for (auto& p : ev_pairs) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
         if (stage_free) (void)hipEventDestroy(stage_free);
         void* ptrs[] = {utMeasNow, utMeasSum, utG[0], utG[1], utG[2], utTmp, utErr, utL[0], utL[1], utD[0], utD[1], utR[0], utR[1], utP[0], utP[1], meas_now, meas_sum, GT, slice_sync, prep, stackP, expK, invexpK, fields, expv, invexpv, tabs, tab8, G, Gtmp, bb0, bb1, stackL, stackD, stackR, tmpL, tmpD, tmpR,
-                        logdet, rs_perm, rs_k, rs_u, Upanel, Wpanel, Cpanel, state, acc, err, dstats, r1scratch};
+                        logdet, rs_perm, rs_k, rs_u, Upanel, Wpanel, Cpanel, ibuf, ijp, state, acc, err, dstats, r1scratch};
         for (void* p : ptrs) if (p) (void)hipFree(p);
         if (h_stage) (void)hipHostFree(h_stage);
     }
@@ -344,11 +345,52 @@ struct Engine {
     }
     // DQMC::init_stacks + init_greenfunctions (source/dqmc.cpp:43-72)
     int init() {
+        // Single chain, N <= 256, whole blocks: the n_stack products Bbar_i and their to_LDR factorisations do not depend on each
+        // other (source/dqmc.cpp:47-53 computes them one after the other), so they run as ONE batch with the block index in the
+        // kernels' chain dimension -- n_stab - 1 launches of the 64x64-tile GEMM for all blocks, one QRCP launch with a workgroup
+        // per block on its own CU (20 x 0.84 ms side by side instead of in a row) -- and only the n_stack - 1 ldr_mul_ldr products,
+        // which are a chain, stay sequential.  Halves the cost of an initialisation, i.e. of a replica-exchange round.
+        static const bool no_batch = getenv("DQMC_INIT_SEQUENTIAL") != nullptr;      // A/B switch
+        if (C == 1 && n <= 256 && nt % n_stab == 0 && n_stack >= 2 && !no_batch) return init_batched();
         LdrRef tmp{Mat{tmpL, nn}, Vec{tmpD, (long)n}, Mat{tmpR, nn}};
         for (int i = n_stack - 1; i >= 0; --i) {
             Mat bb; DQ_TRY(Bbar(i, &bb));
             if (i == n_stack - 1) DQ_TRY(ctx.to_ldr(bb, stk(i)));
             else { DQ_TRY(ctx.to_ldr(bb, tmp)); DQ_TRY(ctx.ldr_mul_ldr(stk(i + 1), tmp, stk(i))); }
+        }
+        stack_valid = true;
+        gt_valid = false;
+        return ctx.inv_I_plus_ldr(stk(0), mG(), logdet);
+    }
+    int init_batched() {
+        const int S = n_stack;
+        if (!ibuf) {
+            DQ_TRY(dalloc(&ibuf, (size_t)4 * S * nn + (size_t)2 * S * n));
+            DQ_TRY(dalloc(&ijp, (size_t)S * n));
+        }
+        double* ib0 = ibuf; double* ib1 = ib0 + (size_t)S * nn; double* iL = ib1 + (size_t)S * nn; double* iR = iL + (size_t)S * nn;
+        double* iD = iR + (size_t)S * nn; double* iTau = iD + (size_t)S * n;
+        const long bstride = (long)n_stab * n;                                            // exp(V) of block i starts n_stab slices further
+        Mat cur{ib0, nn}, nxt{ib1, nn};
+        DQ_TRY(launch_scale_rows(CMat(expK, 0), CVec(expv, bstride), cur, n, S, s));        // B_l0 of every block
+        for (int loc = 1; loc < n_stab; ++loc) {
+            GemmDesc g; g.A = CMat(expK, 0); g.B = cur; g.C = nxt; g.rs = CVec(expv + (long)loc * n, bstride); g.n = n;
+            DQ_TRY(launch_gemm(g, S, s));                                                 // B_l * Bbar, all blocks
+            std::swap(cur, nxt);
+        }
+        QrWork w{iTau, (long)n, ijp, (long)n};
+        w.info = ctx.info();
+        DQ_TRY(launch_to_ldr(cur, Mat{iL, nn}, Vec{iD, (long)n}, Mat{iR, nn}, w, n, S, s));   // to_LDR(Bbar_i) for every block
+        // stack[S - 1] = its own factorisation (R a single permuted-triangular factor), then the chain of products
+        LdrRef last = stk(S - 1);
+        DQ_TRY(launch_copy(CMat(iL + (size_t)(S - 1) * nn, nn), last.L, nn, 1, s));
+        DQ_TRY(launch_copy(CMat(iR + (size_t)(S - 1) * nn, nn), last.R, nn, 1, s));
+        DQ_HIP(hipMemcpyAsync(last.d.p, iD + (size_t)(S - 1) * n, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
+        DQ_HIP(hipMemcpyAsync(last.jpvt, ijp + (size_t)(S - 1) * n, sizeof(int) * n, hipMemcpyDeviceToDevice, s));
+        *last.tri = true;
+        for (int i = S - 2; i >= 0; --i) {
+            LdrRef tmp{Mat{iL + (size_t)i * nn, nn}, Vec{iD + (size_t)i * n, (long)n}, Mat{iR + (size_t)i * nn, nn}};
+            DQ_TRY(ctx.ldr_mul_ldr(stk(i + 1), tmp, stk(i)));
         }
         stack_valid = true;
         gt_valid = false;

@@ -362,7 +362,8 @@ def test_set_G_and_reinit_are_consistent(hip, orc):
 
 def test_alternative_kernel_paths_in_subprocess(hip):
     """Every env-switch kernel variant that is still shipped (the sub-matrix walk, the scan / flush kernel pairs, the solo slice
-    kernel, dgetrf + dgetrs instead of Gauss-Jordan, the single-wave Gauss-Jordan panel, the streaming QRCP, the unblocked form-Q)
+    kernel, dgetrf + dgetrs instead of Gauss-Jordan, the single-wave Gauss-Jordan panel, the streaming QRCP, the unblocked form-Q,
+    the block-by-block initialisation)
     runs the golden fixtures in a fresh process (the switches are read once per process) and is compared ELEMENT-WISE with the
     independent numpy evaluation stored there: G(0,0), log det, G and the HS fields after a full sweep at cfg 2 and cfg 3, and the
     same for every chain of a 4-chain batched engine at cfg 2."""
@@ -389,7 +390,7 @@ def test_alternative_kernel_paths_in_subprocess(hip):
         assert out.returncode == 0, (env_extra, out.stderr[-2000:])
         return json.loads(out.stdout.strip().splitlines()[-1])
     for env in ({}, {"DQMC_WALK_SUBMATRIX": "1"}, {"DQMC_SLICE_MULTIKERNEL": "1"}, {"DQMC_SLICE_PAIRS": "1"}, {"DQMC_SLICE_SOLO": "1"}, {"DQMC_LU_CLASSIC": "1"},
-                {"DQMC_GJ_PANEL_1W": "1"}, {"DQMC_QR_STREAMING": "1"}, {"DQMC_FORMQ_CLASSIC": "1"}):
+                {"DQMC_GJ_PANEL_1W": "1"}, {"DQMC_QR_STREAMING": "1"}, {"DQMC_FORMQ_CLASSIC": "1"}, {"DQMC_INIT_SEQUENTIAL": "1"}):
         got = run(env)
         print(env, {k: (v["d0"], v["dA"]) if "d0" in v else v["dA"] for k, v in got.items()})
         for name in ("cfg2_therm", "cfg3_therm"):
