@@ -124,6 +124,7 @@ int run_rank(const RunConfig& rc, int rank, int world_size, int device, dqmc_com
         catch (const std::exception& e) { std::cerr << "warning: no HDF5 output (" << e.what() << ")\n"; }
     }
     const long bin_sweeps = (long)n_bins * n_sweeps;
+    double warned_err = 0.0;
     const auto t1 = std::chrono::steady_clock::now();
     for (long isweep = 1; isweep <= bin_sweeps; ++isweep) {
         if (pt_enabled && (isweep % exchange_step == 0)) {                                     // source/main.cpp:146-153
@@ -137,6 +138,13 @@ int run_rank(const RunConfig& rc, int rank, int world_size, int device, dqmc_com
         sim.measure_unequal(lat);                                  // the dynamical observables of the same call, when isMeasureUnequalTime
         if (isweep % n_sweeps == 0) {                              // measurements.accumulate(lat), :167-169: one bin done
             const DQMC::EqualTime bin = sim.fetch_bin(lat);
+            // the reference warns at every stabilisation whose wrap-vs-stabilised difference exceeds 1e-6 (source/dqmc.cpp:390-393,
+            // :450-453); the engine folds the errors on the device, so the check runs where the host synchronises anyway: once per bin
+            if (const double me = sim.max_err(); me > 1e-6 && me > warned_err) {
+                std::lock_guard<std::mutex> lk(g_print_mu);
+                std::cerr << "WARNING: GF precision > 1e-6 (rank " << rank << "). Reduce n_stab or increasing nt. Error: " << me << std::endl;
+                warned_err = me;
+            }
             ResultsBin rb; rb.density = bin.density; rb.doubleOcc = bin.doubleOcc; rb.swave = bin.swave; rb.densityCorr_r = bin.densityCorr_r;
             std::vector<double> ut;
             const int nt_ = params.getInt("simulation", "nt");
