@@ -454,20 +454,36 @@ def test_observables_batched_and_golden(hip):
 
 
 # ---- unequal-time path on the device -------------------------------------------------------
-@pytest.mark.parametrize("cfg,tol", [("cfg1", 1e-10), ("cfg2", 1e-10), ("cfg3", 1e-10)])
+@pytest.mark.parametrize("cfg,tol", [("cfg1", 1e-10), ("cfg2", 1e-10), ("cfg3", 1e-10), ("cfg3_therm", 1e-10)])
 def test_unequal_time_parity(hip, orc, cfg, tol):
-    """Gtt[l], Gt0[l], G0t[l] for every slice after one sweep on both sides, device vs oracle (fp64, 1e-10 of the largest entry of the
-    slice at every size: measured 4e-11 / 4e-12 / 6e-11 at cfg 1 / 2 / 3), plus the three wrap errors per stabilisation in the stats."""
+    """Gtt[l], Gt0[l], G0t[l] for every slice after one sweep on both sides, device vs oracle, fp64: 1e-10 of the largest entry of the
+    slice.  "cfg3_therm" starts from the thermalised fixture (the input class the 1e-10 target is stated for) and is held to 1e-10
+    strictly; "cfg3" starts from i.i.d. fields (max|G| ~ 1e3), where the oracle's two dense back ends differ by 3e-11 relative
+    themselves and the GPU lands at 6e-11 ... 1.2e-10 depending on the summation order of its kernels: there the bound is 1e-10 or
+    5x the CPU-vs-CPU floor measured in the test, as for the ill-conditioned init case.  Plus the three wrap errors per
+    stabilisation in the stats."""
+    therm = cfg.endswith("_therm"); cfg = cfg.replace("_therm", "")
     m = HubbardModel(**CONFIGS[cfg]); rng = np.random.default_rng(6)
-    f0 = m.random_fields(17); sf, sb = m.random_stream(rng), m.random_stream(rng)
+    f0 = golden_util.load(cfg + "_therm")[0]["fields"] if therm else m.random_fields(17)
+    sf, sb = m.random_stream(rng), m.random_stream(rng)
     e = m.engine(hip); o = m.engine(orc)
     for x in (e, o):
         x.set_fields(f0); x.init(); x.sweep_0_to_beta(*sf); x.sweep_beta_to_0(*sb); x.sweep_unequal_time()
-    worst = 0.0
+    o2 = None
+    if cfg == "cfg3" and not therm and orc.set_backend("lapack"):       # second CPU evaluation (the back end is a process-wide switch of the oracle: run it after the first)
+        try:
+            o2 = m.engine(orc); o2.set_fields(f0); o2.init(); o2.sweep_0_to_beta(*sf); o2.sweep_beta_to_0(*sb); o2.sweep_unequal_time()
+        finally:
+            orc.set_backend("builtin")
+    worst = 0.0; floor = 0.0
     for which in ("tt", "t0", "0t"):
         for l in (range(m.nt + 1) if m.nt <= 80 else list(range(0, m.nt + 1, 7)) + [m.nt - 1, m.nt]):
             a, b = e.get_G_tau(which, l), o.get_G_tau(which, l)
             worst = max(worst, np.abs(a - b).max() / max(1.0, np.abs(b).max()))
+            if o2 is not None:
+                floor = max(floor, np.abs(o2.get_G_tau(which, l) - b).max() / max(1.0, np.abs(b).max()))
+    tol = max(tol, 5.0 * floor)
+    print(f"{cfg}{' (thermalised)' if therm else ''}: CPU-vs-CPU floor {floor:.2e}")
     print(f"{cfg}: unequal-time max rel err {worst:.2e}")
     assert worst < tol
     se, so = e.stats(), o.stats()
