@@ -1,8 +1,8 @@
 // qr_colown.hip -- column-pivoted Householder QR for n <= 256, "column-owner" layout, one workgroup per chain.
-// Same algorithm and output format as qrcp_onchip_kernel / the streaming qrcp_kernel (LAPACK dlaqp2 semantics:
-// reflectors and R0 left in place in A without column swaps, jpvt / tau out); to_LDR = source/stablelinalg.cpp:35-55.
+// Same algorithm and output format as the streaming qrcp_kernel of qr.hip and the cooperative kernel of qr_coop.hip (LAPACK
+// dlaqp2 semantics: reflectors and R0 left in place in A without column swaps, jpvt / tau out); to_LDR = source/stablelinalg.cpp:35-55.
 //
-// Why another layout.  The 2-D block-cyclic kernel of qr_onchip.hip spends ~11500 clk per step (stamps): every
+// Why this layout.  A 2-D block-cyclic single-workgroup kernel (round 1's qr_onchip.hip, deleted) spent ~11500 clk per step (stamps): every
 // phase pays for cross-lane traffic -- the pivot column is gathered through LDS, each v_r is an LDS broadcast read
 // (a broadcast still occupies the LDS pipe for the full 64 lanes), dot products end in DPP row reductions, a quarter
 // of the matrix is read twice and written once in LDS per step, and ~285 VGPRs spill.  Here
