@@ -229,6 +229,9 @@ def main():
                          "(local_rank %% device_count); the timing is meaningless")
     ap.add_argument("--launch-check", action="store_true",
                     help="rendezvous, barrier and max-over-ranks only (gloo, no engine, no GPU): the CPU test of the N > 1 launch path")
+    ap.add_argument("--checkerboard", action="store_true",
+                    help="opt-in: checkerboard break-up of exp(-dtau K) (dqmc_set_checkerboard) instead of the reference's dense exponential -- a "
+                         "different discretisation, reported with \"kinetic\": \"checkerboard\" and never comparable with the headline line")
     ap.add_argument("--no-replica-exchange", action="store_true", help="skip the RCCL replica-exchange rounds after the timed region (N > 1)")
     args = ap.parse_args()
 
@@ -278,6 +281,8 @@ def main():
         fields = np.stack([f0 for _ in range(C)]); start = "thermalised fixture tests/golden/%s_therm.npz + %d warm-up sweeps" % (args.config, args.warmup)
     else:
         fields = np.stack([model.random_fields(12345 + rank * C + c) for c in range(C)]); start = "iid random fields (seed 12345 + chain) + %d warm-up sweeps" % args.warmup
+    if args.checkerboard:
+        eng.set_checkerboard(*model.checkerboard()); args.no_cpu_baseline = True; args.batched_chains = 0
     eng.set_fields(fields); eng.init()
     rng = np.random.default_rng(777 + rank)
 
@@ -324,7 +329,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.config}: {model.L1}x{model.L2} Hubbard U={model.U} beta={model.beta} Ltau={model.nt} n_stab={model.n_stab} t=1 mu=-0.1",
                        "chains_per_gpu": C, "n_chains_total": world * C, "parallelism": f"independent chains, {world} gpu x {C} chain"},
-            "start": start,
+            "start": start, "kinetic": "checkerboard" if args.checkerboard else "dense exp(-dtau K) (the reference's)",
             "acceptance": acc_rate, "max_wrap_err": s1.max_err, "mean_wrap_err": s1.mean_err,
             "roofline": {"kernel": "local update of one time slice (" + ("slice_kernel: delayed-update walk + flush roles" if n <= 256 else
                                                                          "slice_sm_kernel: sub-matrix walk + flush roles") + ")", "bound": "hbm",
@@ -348,7 +353,7 @@ def main():
         eng.sync(); tg = (time.perf_counter() - tg0) / (4 * n_pairs)
         gflop = 2.0 * n ** 3 * C
         out["gemm_chain"].update({"avg_gemm_us": tg * 1e6, "achieved_tflops": gflop / tg / 1e12, "frac": gflop / tg / 1e12 / FP64_MFMA_PEAK_TFLOPS,
-                                  "bound": "mfma", "note": "one 256^3 GEMM is launch/latency bound; the batched engines run the same chain at 41 TFLOP/s (DESIGN.md 4)"})
+                                  "bound": "mfma", "note": "checkerboard: these are the pair kernels, not GEMMs" if args.checkerboard else "one 256^3 GEMM is launch/latency bound; the batched engines run the same chain at 41 TFLOP/s (DESIGN.md 4)"})
         if world == 1 and args.batched_chains > 1 and C == 1:
             # throughput mode: the same kernels advance B independent chains per launch (blockIdx.y = chain), optionally spread
             # over E engines (own HIP stream and host thread each).  The random streams are drawn before the clock starts: with

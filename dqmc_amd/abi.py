@@ -45,7 +45,7 @@ ABI_SYMBOLS = [
     "gemm", "rank1_update",
     "create", "create_batch", "n_chains", "destroy", "set_fields", "get_fields", "init", "get_G", "set_G", "get_logdet",
     "n_stack", "get_stack", "sweep_0_to_beta", "sweep_beta_to_0", "sync", "get_stats",
-    "wrap_forward", "wrap_backward", "local_update_slice", "calculate_Bbar", "global_action",
+    "wrap_forward", "wrap_backward", "local_update_slice", "calculate_Bbar", "global_action", "set_checkerboard",
     "update_kernel_time", "set_profiling",
     "measure_equal_time", "measure_accumulate", "measure_fetch",
     "sweep_unequal_time", "get_G_tau", "measure_unequal_time", "measure_unequal_fetch",
@@ -108,6 +108,7 @@ class DqmcLib:
             g(name).argtypes = [C.c_void_p, C.c_int]
         g("local_update_slice").argtypes = [C.c_void_p, C.c_int, c_int32_p, c_uint8_p, c_double_p, C.c_void_p]
         g("calculate_Bbar").argtypes = [C.c_void_p, C.c_int, c_double_p]
+        g("set_checkerboard").argtypes = [C.c_void_p, C.c_int, c_int32_p, c_int32_p, c_double_p, c_double_p, c_double_p]
         g("update_kernel_time").argtypes = [C.c_void_p, c_double_p, c_int64_p, c_int64_p]
         g("set_profiling").argtypes = [C.c_void_p, C.c_int]
         if self.has_symbol("measure_equal_time"):
@@ -409,6 +410,15 @@ class Engine:
 
     def calculate_Bbar(self, i_stack: int) -> np.ndarray:
         B = np.empty(self.C * self.n * self.n); self._c("calculate_Bbar", int(i_stack), _p(B)); return self._mats_out(B)
+
+    def set_checkerboard(self, groups, cosh_t, sinh_t, diag_factor):
+        """dqmc_set_checkerboard: `groups` = list of bond groups, each a sequence of (i, j) site pairs; the three
+        parameters are scalars or one value per chain.  Call before init()."""
+        sizes = np.ascontiguousarray([len(g) for g in groups], np.int32)
+        flat = [p for g in groups for p in g]
+        bonds = np.ascontiguousarray(np.asarray(flat, np.int32).reshape(-1, 2) if flat else np.zeros((1, 2), np.int32))
+        par = [np.ascontiguousarray(np.broadcast_to(np.asarray(x, np.float64), (self.C,))) for x in (cosh_t, sinh_t, diag_factor)]
+        self._c("set_checkerboard", len(groups), bonds.ctypes.data_as(c_int32_p), sizes.ctypes.data_as(c_int32_p), _p(par[0]), _p(par[1]), _p(par[2]))
 
     def global_action(self):
         v = np.zeros(self.C); self._c("global_action", _p(v)); return v if self.batched else float(v[0])

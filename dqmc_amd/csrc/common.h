@@ -179,6 +179,22 @@ bool slice_persistent_allowed(int device);    // false while more than three eng
 // standalone Sherman-Morrison rank-1 update (source/model.cpp:124-138), whole-chip streaming kernel
 int launch_rank1(Mat G, int i, double delta, double* scratch /*2n+1 doubles per chain*/, long scratch_stride, int n, int n_chains, hipStream_t s);
 
+// ---- checkerboard.hip -----------------------------------------------------------
+// out = diag(rs_out) * [ E^(+-1) * (diag(rs_in) * in * diag(cs_in)) ] * diag(cs_out), and / or its transpose into outT, where
+// E = f * E_{G-1} ... E_0 is the checkerboard break-up of exp(-dtau K) (README.md:40): E_g mixes the site pairs (r, partner[g][r])
+// with [cosh sinh; sinh cosh].  reverse: run the groups G-1 .. 0 instead of 0 .. G-1; inverse: sinh -> -sinh, f -> 1/f.
+// E^-1 * M is (reverse, inverse); M * E^(+-1) is the same launch on M^T (E_g symmetric).  `out` may alias `in`, `outT` may not.
+struct CbDesc {
+    CMat in;
+    Mat out{nullptr, 0}, outT{nullptr, 0};
+    const int* partner = nullptr;             // [n_groups][n]; partner[g][r] == r: site r is in no pair of group g
+    int n_groups = 0, reverse = 0, inverse = 0;
+    const double* par = nullptr; long par_stride = 0;   // per chain {cosh, sinh, f, 1/f}
+    CVec rs_in, cs_in, rs_out, cs_out;        // null = identity
+    int n = 0;
+};
+int launch_cb_apply(const CbDesc& d, int n_chains, hipStream_t s);
+
 // ---- per-device kernel attributes (dynamic LDS > 64 KiB), set once per device by init_device_kernels (engine.hip) ----
 int update_init_device();
 int update_sm_init_device();

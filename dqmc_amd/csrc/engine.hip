@@ -212,6 +212,10 @@ struct Engine {
     hipStream_t s = nullptr;
 
     double* expK = nullptr; double* invexpK = nullptr;           // [C][nn]
+    // checkerboard break-up of exp(-+dtau K) (dqmc_set_checkerboard): wraps and B-bar products apply the pair factors directly
+    bool cb = false; int cb_groups = 0;
+    int* cb_partner = nullptr;                                   // [cb_groups][n]
+    double* cb_par = nullptr;                                    // [C][4] cosh, sinh, f, 1/f
     int8_t* fields = nullptr;                                    // [C][nt][n]
     double* expv = nullptr; double* invexpv = nullptr;           // [C][nt][n]
     UpdateTables* tabs = nullptr; double* tab8 = nullptr;        // [C], [C][8]
@@ -268,7 +272,7 @@ struct Engine {
         if (counted) slice_engine_destroyed(device);
         for (auto& p : ev_pairs) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
         if (stage_free) (void)hipEventDestroy(stage_free);
-        void* ptrs[] = {utMeasNow, utMeasSum, utG[0], utG[1], utG[2], utTmp, utErr, utL[0], utL[1], utD[0], utD[1], utR[0], utR[1], utP[0], utP[1], meas_now, meas_sum, GT, slice_sync, prep, stackP, expK, invexpK, fields, expv, invexpv, tabs, tab8, G, Gtmp, bb0, bb1, stackL, stackD, stackR, tmpL, tmpD, tmpR,
+        void* ptrs[] = {utMeasNow, utMeasSum, utG[0], utG[1], utG[2], utTmp, utErr, utL[0], utL[1], utD[0], utD[1], utR[0], utR[1], utP[0], utP[1], meas_now, meas_sum, GT, slice_sync, prep, stackP, expK, invexpK, cb_partner, cb_par, fields, expv, invexpv, tabs, tab8, G, Gtmp, bb0, bb1, stackL, stackD, stackR, tmpL, tmpD, tmpR,
                         logdet, rs_perm, rs_k, rs_u, Upanel, Wpanel, Cpanel, ibuf, ijp, state, acc, err, dstats, r1scratch};
         for (void* p : ptrs) if (p) (void)hipFree(p);
         if (h_stage) (void)hipHostFree(h_stage);
@@ -332,13 +336,59 @@ struct Engine {
         return 0;
     }
 
+    // one launch of the checkerboard kernel on this engine's pair tables (chains / par_stride differ for the batched initialisation)
+    int cb_apply(CMat in, Mat out, Mat outT, bool reverse, bool inverse, CVec rs_in, CVec cs_in, CVec rs_out, CVec cs_out, int chains, long par_stride) {
+        CbDesc d; d.in = in; d.out = out; d.outT = outT; d.partner = cb_partner; d.n_groups = cb_groups; d.reverse = reverse ? 1 : 0; d.inverse = inverse ? 1 : 0;
+        d.par = cb_par; d.par_stride = par_stride; d.rs_in = rs_in; d.cs_in = cs_in; d.rs_out = rs_out; d.cs_out = cs_out; d.n = n;
+        return launch_cb_apply(d, chains, s);
+    }
+    // dqmc_set_checkerboard: pair tables to the device, then E and E^-1 as dense matrices (the kernel applied to I) for the
+    // paths that stay GEMMs (the unequal-time series and the first factor of a B-bar product)
+    int set_checkerboard(int n_groups, const int32_t* bonds, const int32_t* group_sizes, const double* ch, const double* sh, const double* f) {
+        if (n_groups < 1 || n_groups > 64 || !bonds || !group_sizes || !ch || !sh || !f) { set_error("set_checkerboard: bad argument"); return DQMC_EINVAL; }
+        if (n > 4096) { set_error("set_checkerboard: n_sites > 4096"); return DQMC_EINVAL; }
+        std::vector<int> partner((size_t)n_groups * n);
+        size_t b = 0;
+        for (int g = 0; g < n_groups; ++g) {
+            int* pt = partner.data() + (size_t)g * n;
+            for (int i = 0; i < n; ++i) pt[i] = i;
+            if (group_sizes[g] < 0 || group_sizes[g] > n / 2) { set_error("set_checkerboard: a group holds at most n_sites/2 bonds"); return DQMC_EINVAL; }
+            for (int k = 0; k < group_sizes[g]; ++k, ++b) {
+                const int i = bonds[2 * b], j = bonds[2 * b + 1];
+                if (i < 0 || i >= n || j < 0 || j >= n || i == j) { set_error("set_checkerboard: bond site out of range"); return DQMC_EINVAL; }
+                if (pt[i] != i || pt[j] != j) { set_error("set_checkerboard: the bonds of one group must be disjoint"); return DQMC_EINVAL; }
+                pt[i] = j; pt[j] = i;
+            }
+        }
+        std::vector<double> par((size_t)C * 4);
+        for (int c = 0; c < C; ++c) {
+            if (!(f[c] > 0.0) || !std::isfinite(ch[c]) || !std::isfinite(sh[c])) { set_error("set_checkerboard: diag_factor must be positive, cosh / sinh finite"); return DQMC_EINVAL; }
+            par[4 * c] = ch[c]; par[4 * c + 1] = sh[c]; par[4 * c + 2] = f[c]; par[4 * c + 3] = 1.0 / f[c];
+        }
+        DQ_HIP(hipStreamSynchronize(s));
+        if (cb_partner) { (void)hipFree(cb_partner); cb_partner = nullptr; }
+        DQ_TRY(dalloc(&cb_partner, partner.size()));
+        if (!cb_par) DQ_TRY(dalloc(&cb_par, (size_t)C * 4));
+        DQ_HIP(hipMemcpy(cb_partner, partner.data(), sizeof(int) * partner.size(), hipMemcpyHostToDevice));
+        DQ_HIP(hipMemcpy(cb_par, par.data(), sizeof(double) * par.size(), hipMemcpyHostToDevice));
+        cb_groups = n_groups; cb = true;
+        Mat id{bb0, nn};
+        DQ_TRY(launch_set_identity(id, n, C, s));
+        DQ_TRY(cb_apply(id, Mat{expK, nn}, Mat{nullptr, 0}, false, false, CVec(), CVec(), CVec(), CVec(), C, 4));      // E = f E_{G-1} ... E_0
+        DQ_TRY(cb_apply(id, Mat{invexpK, nn}, Mat{nullptr, 0}, true, true, CVec(), CVec(), CVec(), CVec(), C, 4));     // E^-1 = E_0^-1 ... E_{G-1}^-1 / f
+        stack_valid = false; gt_valid = false; ut_valid = false;
+        DQ_HIP(hipStreamSynchronize(s));
+        return 0;
+    }
+
     // DQMC::calculate_Bbar (source/dqmc.cpp:88-105) without the multiply by I: result in *out
     int Bbar(int is, Mat* out) {
         const int l0 = is * n_stab;
         Mat cur{bb0, nn}, nxt{bb1, nn};
         DQ_TRY(launch_scale_rows(CMat(expK, nn), ev(l0), cur, n, C, s));                  // B_l0 = diag(expV) expK
         for (int loc = 1; loc <= loc_l_end[is]; ++loc) {
-            DQ_TRY(ctx.gemm(CMat(expK, nn), cur, nxt, ev(l0 + loc)));                     // B_l * Bbar
+            if (cb) DQ_TRY(cb_apply(cur, nxt, Mat{nullptr, 0}, false, false, CVec(), CVec(), ev(l0 + loc), CVec(), C, 4));
+            else DQ_TRY(ctx.gemm(CMat(expK, nn), cur, nxt, ev(l0 + loc)));                // B_l * Bbar
             std::swap(cur, nxt);
         }
         *out = cur; return 0;
@@ -374,8 +424,11 @@ struct Engine {
         Mat cur{ib0, nn}, nxt{ib1, nn};
         DQ_TRY(launch_scale_rows(CMat(expK, 0), CVec(expv, bstride), cur, n, S, s));        // B_l0 of every block
         for (int loc = 1; loc < n_stab; ++loc) {
-            GemmDesc g; g.A = CMat(expK, 0); g.B = cur; g.C = nxt; g.rs = CVec(expv + (long)loc * n, bstride); g.n = n;
-            DQ_TRY(launch_gemm(g, S, s));                                                 // B_l * Bbar, all blocks
+            if (cb) DQ_TRY(cb_apply(cur, nxt, Mat{nullptr, 0}, false, false, CVec(), CVec(), CVec(expv + (long)loc * n, bstride), CVec(), S, 0));
+            else {
+                GemmDesc g; g.A = CMat(expK, 0); g.B = cur; g.C = nxt; g.rs = CVec(expv + (long)loc * n, bstride); g.n = n;
+                DQ_TRY(launch_gemm(g, S, s));                                             // B_l * Bbar, all blocks
+            }
             std::swap(cur, nxt);
         }
         QrWork w{iTau, (long)n, ijp, (long)n};
@@ -398,12 +451,24 @@ struct Engine {
     }
     // DQMC::propagate_GF_forward (source/dqmc.cpp:113-132): G = B_l G B_l^-1
     int wrap_forward(int l) {
+        if (cb) {
+            // T^T = (E G)^T;  (T E^-1)^T = E^-T T^T with E^-T = E_{G-1}^-1 ... E_0^-1 / f: groups 0 .. G-1, inverse;  G' = diag(ev) (T E^-1) diag(iev)
+            DQ_TRY(cb_apply(mG(), Mat{nullptr, 0}, ctx.T(0), false, false, CVec(), CVec(), CVec(), CVec(), C, 4));
+            gt_valid = use_gt();
+            return cb_apply(ctx.T(0), Mat{GT, nn}, mG(), false, true, CVec(), CVec(), iev(l), ev(l), C, 4);
+        }
         DQ_TRY(ctx.gemm(CMat(expK, nn), mG(), ctx.T(0)));
         gt_valid = use_gt();                                          // the GEMM that writes G writes GT as well
         return ctx.gemm(ctx.T(0), CMat(invexpK, nn), mG(), ev(l), CVec(), iev(l), 0, 0, use_gt() ? Mat{GT, nn} : Mat{nullptr, 0});
     }
     // DQMC::propagate_GF_backward (source/dqmc.cpp:169-187): G = B_l^-1 G B_l
     int wrap_backward(int l) {
+        if (cb) {
+            // T^T = (E^-1 diag(iev) G diag(ev))^T;  (T E)^T = E^T T^T with E^T = f E_0 ... E_{G-1}: groups G-1 .. 0, forward
+            DQ_TRY(cb_apply(mG(), Mat{nullptr, 0}, ctx.T(0), true, true, iev(l), ev(l), CVec(), CVec(), C, 4));
+            gt_valid = use_gt();
+            return cb_apply(ctx.T(0), Mat{GT, nn}, mG(), true, false, CVec(), CVec(), CVec(), CVec(), C, 4);
+        }
         DQ_TRY(ctx.gemm(CMat(invexpK, nn), mG(), ctx.T(0), CVec(), iev(l)));
         gt_valid = use_gt();
         return ctx.gemm(ctx.T(0), CMat(expK, nn), mG(), CVec(), ev(l), CVec(), 0, 0, use_gt() ? Mat{GT, nn} : Mat{nullptr, 0});
@@ -728,6 +793,11 @@ int dqmc_create_batch(dqmc_engine** out, int device, int n_chains, int n_sites, 
 int dqmc_create(dqmc_engine** out, int device, int n_sites, int nt, int n_stab, double g, const double gamma[4], const double eta[4],
                 const double* expK, const double* invexpK) {
     return dqmc_create_batch(out, device, 1, n_sites, nt, n_stab, &g, gamma, eta, expK, invexpK);
+}
+int dqmc_set_checkerboard(dqmc_engine* h, int n_groups, const int32_t* bonds, const int32_t* group_sizes, const double* cosh_t, const double* sinh_t,
+                          const double* diag_factor) {
+    CHECK_E(h); Engine& e = h->e; DQ_HIP(hipSetDevice(e.device));
+    return e.set_checkerboard(n_groups, bonds, group_sizes, cosh_t, sinh_t, diag_factor);
 }
 void dqmc_destroy(dqmc_engine* h) { if (h) { (void)hipSetDevice(h->e.device); delete h; } }
 int dqmc_n_chains(dqmc_engine* h) { return h ? h->e.C : 0; }

@@ -242,6 +242,7 @@ class AttractiveHubbard {
     std::vector<double> expK_, invexpK_, expKhalf_, invexpKhalf_;
     GHQField fields_;
     utility::random& rng_;
+    double dtau_ = 0.0; int L1_ = 0, L2_ = 0;
     std::vector<double> build_K_matrix(const Lattice& lat) const {           // source/model.cpp:39-60
         const int n = lat.n_sites(); std::vector<double> K((size_t)n * n, 0.0);
         for (int i = 0; i < n; ++i) {
@@ -256,12 +257,50 @@ public:
         t_ = params.getDouble("hubbard", "t"); mu_ = params.getDouble("hubbard", "mu");
         ns_ = lat.n_cells(); nt_ = (int)params.getDouble("simulation", "nt");
         const double U = params.getDouble("hubbard", "U"), dtau = replica_beta / nt_;
+        dtau_ = dtau; L1_ = lat.L1(); L2_ = lat.L2();
         fields_ = GHQField(nt_, ns_, rng);
         g_ = std::sqrt(0.5 * std::abs(U) * dtau); alpha_ = -1.0;
         std::vector<double> K = build_K_matrix(lat), S(K.size());
         auto scaled = [&](double f) { for (size_t k = 0; k < K.size(); ++k) S[k] = f * K[k]; return dqmc_detail::expm(S, ns_); };
         expK_ = scaled(-dtau); invexpK_ = scaled(dtau); expKhalf_ = scaled(-0.5 * dtau); invexpKhalf_ = scaled(0.5 * dtau);
     }
+    // Checkerboard break-up of exp(-dtau K) (the reference's README.md:40 lists it as future work; opt-in through
+    // [simulation] checkerboard = true, see DQMC's constructor): the distinct bonds build_K_matrix sets to -t, split into groups
+    // of disjoint pairs -- x bonds from even / odd columns and y bonds from even / odd rows when both lengths are even and >= 4,
+    // a greedy edge colouring of the same bond list otherwise (dqmc_amd/model.py: checkerboard_groups is the same rule).
+    std::vector<std::vector<std::array<int, 2>>> checkerboard_groups() const {
+        if (L1_ < 2 || L2_ < 2) throw std::invalid_argument("checkerboard break-up needs L1, L2 >= 2");
+        std::vector<std::vector<std::array<int, 2>>> groups;
+        auto site = [&](int x, int y) { return ((y % L2_ + L2_) % L2_) * L1_ + ((x % L1_ + L1_) % L1_); };
+        if (L1_ % 2 == 0 && L2_ % 2 == 0 && L1_ >= 4 && L2_ >= 4) {
+            for (int p = 0; p < 2; ++p) { groups.emplace_back(); for (int y = 0; y < L2_; ++y) for (int x = p; x < L1_; x += 2) groups.back().push_back({site(x, y), site(x + 1, y)}); }
+            for (int p = 0; p < 2; ++p) { groups.emplace_back(); for (int x = 0; x < L1_; ++x) for (int y = p; y < L2_; y += 2) groups.back().push_back({site(x, y), site(x, y + 1)}); }
+            return groups;
+        }
+        std::vector<std::array<int, 2>> bonds;
+        for (int i = 0; i < ns_; ++i) {
+            const int x = i % L1_, y = i / L1_;
+            for (int j : {site(x + 1, y), site(x, y + 1)}) {
+                const std::array<int, 2> key{std::min(i, j), std::max(i, j)};
+                bool seen = (i == j);
+                for (const auto& b : bonds) if (std::min(b[0], b[1]) == key[0] && std::max(b[0], b[1]) == key[1]) { seen = true; break; }
+                if (!seen) bonds.push_back({i, j});
+            }
+        }
+        for (const auto& b : bonds) {
+            bool placed = false;
+            for (auto& g : groups) {
+                bool free_ = true;
+                for (const auto& q : g) if (q[0] == b[0] || q[1] == b[0] || q[0] == b[1] || q[1] == b[1]) { free_ = false; break; }
+                if (free_) { g.push_back(b); placed = true; break; }
+            }
+            if (!placed) groups.push_back({b});
+        }
+        return groups;
+    }
+    double cosh_dtau_t() const { return std::cosh(dtau_ * t_); }
+    double sinh_dtau_t() const { return std::sinh(dtau_ * t_); }
+    double exp_dtau_mu() const { return std::exp(dtau_ * mu_); }
     const std::vector<double>& expK(int) const { return expK_; }
     const std::vector<double>& invexpK(int) const { return invexpK_; }
     const std::vector<double>& expK_half(int) const { return expKhalf_; }
@@ -376,6 +415,13 @@ public:
         const GHQField& f = model.fields();
         dqmc_detail::check(dqmc_create(&e_, device, model.ns(), nt_, n_stab_, model.g(), f.gamma_table().data(), f.eta_table().data(),
                                        model.expK(0).data(), model.invexpK(0).data()));
+        if (params.getBool("simulation", "checkerboard", false)) {      // extension key (README.md:40 of the reference: future work); default: dense exp
+            const auto groups = model.checkerboard_groups();
+            std::vector<int32_t> bonds, sizes;
+            for (const auto& g : groups) { sizes.push_back((int32_t)g.size()); for (const auto& b : g) { bonds.push_back(b[0]); bonds.push_back(b[1]); } }
+            const double c = model.cosh_dtau_t(), s = model.sinh_dtau_t(), f = model.exp_dtau_mu();
+            dqmc_detail::check(dqmc_set_checkerboard(e_, (int)groups.size(), bonds.data(), sizes.data(), &c, &s, &f));
+        }
         const size_t cnt = (size_t)nt_ * model.ns(); perm_.resize(cnt); kprop_.resize(cnt); u_.resize(cnt);
     }
     ~DQMC() { dqmc_destroy(e_); }

@@ -80,6 +80,29 @@ int dqmc_host_model(const char* ini, double beta, unsigned int seed, int* ns, in
     }
 }
 
+// AttractiveHubbard::checkerboard_groups of the INI's lattice: bonds[2 * max_bonds] group after group, sizes[max_groups], par = {cosh, sinh, exp(dtau mu)};
+// returns the number of groups, or -1 with *err filled
+int dqmc_host_checkerboard_groups(const char* ini, double beta, int32_t* bonds, int max_bonds, int32_t* sizes, int max_groups, double* par, char* err, int errlen) {
+    try {
+        utility::parameters params = utility::parameters::from_string(ini);
+        utility::random rng(1);
+        Lattice lat(params, {1.0, 0.0}, {0.0, 1.0}, {{0.0, 0.0}});
+        AttractiveHubbard model(params, lat, rng, beta);
+        const auto groups = model.checkerboard_groups();
+        if ((int)groups.size() > max_groups) throw std::length_error("too many groups");
+        int b = 0;
+        for (size_t g = 0; g < groups.size(); ++g) {
+            sizes[g] = (int32_t)groups[g].size();
+            for (const auto& q : groups[g]) { if (b >= max_bonds) throw std::length_error("too many bonds"); bonds[2 * b] = q[0]; bonds[2 * b + 1] = q[1]; ++b; }
+        }
+        if (par) { par[0] = model.cosh_dtau_t(); par[1] = model.sinh_dtau_t(); par[2] = model.exp_dtau_mu(); }
+        return (int)groups.size();
+    } catch (const std::exception& e) {
+        if (err && errlen > 0) { std::strncpy(err, e.what(), errlen - 1); err[errlen - 1] = 0; }
+        return -1;
+    }
+}
+
 // INI reader probes: kind 0 = int, 1 = double, 2 = bool, 3 = length of double list
 int dqmc_host_param(const char* ini, const char* section, const char* key, int kind, double* out, char* err, int errlen) {
     try {

@@ -40,6 +40,42 @@ def build_K(L1: int, L2: int, t: float, mu: float) -> np.ndarray:
     return K
 
 
+def lattice_bonds(L1: int, L2: int):
+    """The distinct nearest-neighbour bonds (i, j) build_K sets to -t (include/lattice.h:100-107, PBC; a bond reached
+    twice -- L = 2 -- counts once, as the assignment above does).  L = 1 is refused: there the reference's assignment
+    overwrites the diagonal of K with -t, which no bond list can express."""
+    if L1 < 2 or L2 < 2:
+        raise ValueError("checkerboard break-up needs L1, L2 >= 2")
+    n = L1 * L2
+    seen, out = set(), []
+    for i in range(n):
+        ux, uy = i % L1, i // L1
+        for j in (uy * L1 + (ux + 1) % L1, ((uy + 1) % L2) * L1 + ux):
+            key = (min(i, j), max(i, j))
+            if i != j and key not in seen:
+                seen.add(key); out.append((i, j))
+    return out
+
+
+def checkerboard_groups(L1: int, L2: int):
+    """Bond groups of the checkerboard break-up (README.md:40 of the reference lists it as future work): every group is
+    a set of disjoint bonds, so exp(dtau t sum_group(c_i^+ c_j + h.c.)) is a product of independent 2x2 blocks.  Even L:
+    the four classic groups (x bonds from even / odd columns, y bonds from even / odd rows); otherwise a greedy edge
+    colouring of the same bond list (an odd ring needs a third colour per direction)."""
+    groups = []
+    for b in lattice_bonds(L1, L2):
+        for g in groups:
+            if all(b[0] not in q and b[1] not in q for q in g):
+                g.append(b); break
+        else:
+            groups.append([b])
+    if L1 % 2 == 0 and L2 % 2 == 0 and L1 >= 4 and L2 >= 4:
+        site = lambda x, y: (y % L2) * L1 + (x % L1)
+        groups = [[(site(x, y), site(x + 1, y)) for y in range(L2) for x in range(p, L1, 2)] for p in (0, 1)] + \
+                 [[(site(x, y), site(x, y + 1)) for x in range(L1) for y in range(p, L2, 2)] for p in (0, 1)]
+    return groups
+
+
 def expm_sym(A: np.ndarray) -> np.ndarray:
     """exp of a real symmetric matrix by eigendecomposition (the reference
     calls arma::expmat, source/model.cpp:32-35; setup only, not on the path)."""
@@ -74,6 +110,23 @@ class HubbardModel:
     def engine(self, lib, device: int = 0, n_chains=None):
         return lib.engine(self.n, self.nt, self.n_stab, self.g, self.gamma, self.eta, self.expK, self.invexpK,
                           device=device, n_chains=n_chains)
+
+    def checkerboard(self):
+        """(groups, cosh(dtau t), sinh(dtau t), exp(dtau mu)): the arguments of Engine.set_checkerboard for this model."""
+        return (checkerboard_groups(self.L1, self.L2), float(np.cosh(self.dtau * self.t)), float(np.sinh(self.dtau * self.t)),
+                float(np.exp(self.dtau * self.mu)))
+
+    def checkerboard_expK(self, inverse: bool = False) -> np.ndarray:
+        """Dense E = f E_{G-1} ... E_0 (or its inverse) from 2x2 blocks, plain numpy: what the engines must hold after
+        set_checkerboard."""
+        groups, c, s, f = self.checkerboard()
+        E = np.eye(self.n)
+        for g in groups:
+            Eg = np.eye(self.n)
+            for i, j in g:
+                Eg[i, i] = Eg[j, j] = c; Eg[i, j] = Eg[j, i] = -s if inverse else s
+            E = (E @ Eg) if inverse else (Eg @ E)
+        return np.asfortranarray(E / f if inverse else E * f)
 
     def random_fields(self, seed: int) -> np.ndarray:
         """i.i.d. uniform {0,1,2,3} fields, shape (nt, n) (include/field.h:54-57)."""

@@ -193,6 +193,22 @@ int dqmc_calculate_Bbar(dqmc_engine* e, int i_stack, double* Bbar);
 /* AttractiveHubbard::global_action (source/model.cpp:140-159).               */
 int dqmc_global_action(dqmc_engine* e, double* S);
 
+/* ---- checkerboard break-up of the kinetic propagator ------
+ * The reference multiplies by the dense exp(-+dtau K) (source/model.cpp:32-35, source/dqmc.cpp:78-132) and lists
+ * "Checkerboard implementation" as future work (README.md:40).  This call switches an engine to
+ *     exp(-dtau K)  ~=  E = diag_factor * E_{G-1} ... E_1 E_0,       E^-1 = E_0^-1 ... E_{G-1}^-1 / diag_factor,
+ * where every E_g is a product of disjoint 2x2 blocks [cosh_t sinh_t; sinh_t cosh_t] on the site pairs of bond group g
+ * (hopping K_ij = -t: cosh_t = cosh(dtau t), sinh_t = sinh(dtau t); K_ii = -mu: diag_factor = exp(dtau mu)).  The
+ * engine's expK / invexpK become E / E^-1 (an O(dtau^2) Trotter break-up, a different discretisation from the
+ * reference's dense exponential -- opt-in, never the default), and the wraps and B-bar products apply the factors
+ * pair by pair: O(G N^2) work and 2 N^2 doubles of HBM traffic per product instead of an N^3 GEMM.
+ *   bonds:       the site pairs (i, j) of all groups, group after group: [sum(group_sizes)][2]
+ *   group_sizes: [n_groups]; the pairs of one group must be disjoint (sites in no pair of a group pass through)
+ *   cosh_t, sinh_t, diag_factor: one value per chain (chains of a batched engine may differ in dtau)
+ * Call after dqmc_create and before dqmc_init; DQMC_EINVAL on a malformed bond list.                           */
+int dqmc_set_checkerboard(dqmc_engine* e, int n_groups, const int32_t* bonds, const int32_t* group_sizes,
+                          const double* cosh_t, const double* sinh_t, const double* diag_factor);
+
 /* ---- equal-time observables on the device ---------------
  * Observables::calculate_density / calculate_doubleOccupancy / calculate_swavePairing /
  * calculate_densityCorr (source/model.cpp:167-288) of the current G = Gtt[0] (what

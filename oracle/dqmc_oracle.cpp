@@ -395,9 +395,41 @@ struct Engine {
     /* DQMC::calculate_B / calculate_invB, source/dqmc.cpp:78-86 */
     void B(int l, vecd& out) const { vecd v; expV(l, v, 1.0); out.resize((size_t)n * n); diag_mul_mat(n, v.data(), expK.data(), out.data()); }
     void invB(int l, vecd& out) const { vecd v; expV(l, v, -1.0); out.resize((size_t)n * n); mat_mul_diag(n, invexpK.data(), v.data(), out.data()); }
+    /* ---- checkerboard break-up (the reference lists it as future work, README.md:40, so there is no
+     * reference code to follow: this is the textbook construction the HIP path must reproduce).  K's bonds are split into
+     * groups of disjoint pairs; exp(-dtau K) is replaced by E = f E_{G-1} ... E_0 with E_g = prod over its pairs (i, j) of the
+     * 2x2 block [c s; s c] (c = cosh(dtau t), s = sinh(dtau t), f = exp(dtau mu)); E^-1 = E_0^-1 ... E_{G-1}^-1 / f, s -> -s.
+     * cb_left / cb_right multiply a dense matrix by E or E^-1 pair by pair; B_l = diag(expV_l) E as in source/dqmc.cpp:78-80. */
+    bool cb = false; double cb_c = 1.0, cb_s = 0.0, cb_f = 1.0;
+    std::vector<std::vector<std::pair<int, int>>> cb_groups;
+    void cb_pairs_rows(vecd& M, int g, double s) const {                 /* M <- E_g(s) M: rows i, j of every column */
+        for (const auto& b : cb_groups[g]) for (int k = 0; k < n; ++k) {
+            double& x = M[b.first + (size_t)n * k]; double& y = M[b.second + (size_t)n * k];
+            const double xi = x, yj = y; x = cb_c * xi + s * yj; y = s * xi + cb_c * yj;
+        }
+    }
+    void cb_pairs_cols(vecd& M, int g, double s) const {                 /* M <- M E_g(s): columns i, j of every row */
+        for (const auto& b : cb_groups[g]) for (int k = 0; k < n; ++k) {
+            double& x = M[k + (size_t)n * b.first]; double& y = M[k + (size_t)n * b.second];
+            const double xi = x, yj = y; x = cb_c * xi + s * yj; y = s * xi + cb_c * yj;
+        }
+    }
+    void cb_left(vecd& M, bool inverse) const {                          /* E M  or  E^-1 M */
+        const int G = (int)cb_groups.size();
+        if (!inverse) { for (int g = 0; g < G; ++g) cb_pairs_rows(M, g, cb_s); for (double& v : M) v *= cb_f; }
+        else { for (int g = G - 1; g >= 0; --g) cb_pairs_rows(M, g, -cb_s); for (double& v : M) v *= 1.0 / cb_f; }
+    }
+    void cb_right(vecd& M, bool inverse) const {                         /* M E  or  M E^-1 */
+        const int G = (int)cb_groups.size();
+        if (!inverse) { for (int g = G - 1; g >= 0; --g) cb_pairs_cols(M, g, cb_s); for (double& v : M) v *= cb_f; }
+        else { for (int g = 0; g < G; ++g) cb_pairs_cols(M, g, -cb_s); for (double& v : M) v *= 1.0 / cb_f; }
+    }
+    void scale_rows(vecd& M, const vecd& v) const { for (int k = 0; k < n; ++k) for (int r = 0; r < n; ++r) M[r + (size_t)n * k] *= v[r]; }
+    void scale_cols(vecd& M, const vecd& v) const { for (int k = 0; k < n; ++k) for (int r = 0; r < n; ++r) M[r + (size_t)n * k] *= v[k]; }
     /* DQMC::calculate_Bbar, source/dqmc.cpp:88-105 (starts from I, :91) */
     void Bbar(int i_stack, vecd& out) const {
         out.assign((size_t)n * n, 0.0); for (int i = 0; i < n; ++i) out[i + (size_t)n * i] = 1.0;
+        if (cb) { vecd v; for (int loc = 0; loc <= loc_l_end[i_stack]; ++loc) { expV(i_stack * n_stab + loc, v, 1.0); cb_left(out, false); scale_rows(out, v); } return; }
         vecd Bl, T((size_t)n * n);
         for (int loc = 0; loc <= loc_l_end[i_stack]; ++loc) { B(i_stack * n_stab + loc, Bl); gemm(n, Bl.data(), false, out.data(), false, T.data()); out.swap(T); T.resize((size_t)n * n); }
     }
@@ -413,9 +445,13 @@ struct Engine {
     /* DQMC::init_greenfunctions, source/dqmc.cpp:61-72 */
     int init_green() { G.resize((size_t)n * n); return inv_I_plus_ldr(stack[0], G.data(), &logdet); }
     /* DQMC::propagate_GF_forward, source/dqmc.cpp:113-132: G = (B G) invB */
-    void wrap_forward(int l) { vecd b, ib, T((size_t)n * n); B(l, b); invB(l, ib); gemm(n, b.data(), false, G.data(), false, T.data()); gemm(n, T.data(), false, ib.data(), false, G.data()); }
+    void wrap_forward(int l) {
+        if (cb) { vecd v, iv; expV(l, v, 1.0); expV(l, iv, -1.0); cb_left(G, false); scale_rows(G, v); cb_right(G, true); scale_cols(G, iv); return; }
+        vecd b, ib, T((size_t)n * n); B(l, b); invB(l, ib); gemm(n, b.data(), false, G.data(), false, T.data()); gemm(n, T.data(), false, ib.data(), false, G.data()); }
     /* DQMC::propagate_GF_backward, source/dqmc.cpp:169-187: G = (invB G) B */
-    void wrap_backward(int l) { vecd b, ib, T((size_t)n * n); B(l, b); invB(l, ib); gemm(n, ib.data(), false, G.data(), false, T.data()); gemm(n, T.data(), false, b.data(), false, G.data()); }
+    void wrap_backward(int l) {
+        if (cb) { vecd v, iv; expV(l, v, 1.0); expV(l, iv, -1.0); scale_rows(G, iv); cb_left(G, true); scale_cols(G, v); cb_right(G, false); return; }
+        vecd b, ib, T((size_t)n * n); B(l, b); invB(l, ib); gemm(n, ib.data(), false, G.data(), false, T.data()); gemm(n, T.data(), false, b.data(), false, G.data()); }
     /* DQMC::check_error, source/dqmc.cpp:317-329 */
     double check_error(const vecd& A, const vecd& Bm) {
         double e = 0.0; for (size_t k = 0; k < A.size(); ++k) e = std::max(e, std::fabs(A[k] - Bm[k]));
@@ -664,6 +700,27 @@ int orc_create(orc_engine** out, int /*device*/, int n_sites, int nt, int n_stab
     e->expK.assign(expK, expK + (size_t)n_sites * n_sites); e->invexpK.assign(invexpK, invexpK + (size_t)n_sites * n_sites);
     e->fields.assign((size_t)nt * n_sites, 0); e->G.assign((size_t)n_sites * n_sites, 0.0); e->stack.assign(e->n_stack, LDR());
     *out = e; return OK;
+}
+/* dqmc_set_checkerboard of include/dqmc_hip.h; expK / invexpK become the dense E / E^-1 (what the unequal-time path multiplies by) */
+int orc_set_checkerboard(orc_engine* e, int n_groups, const int32_t* bonds, const int32_t* group_sizes, const double* cosh_t, const double* sinh_t, const double* diag_factor) {
+    if (!e || n_groups < 1 || n_groups > 64 || !bonds || !group_sizes || !cosh_t || !sinh_t || !diag_factor) return fail(EINVAL_, "set_checkerboard: bad argument");
+    if (!(diag_factor[0] > 0.0) || !std::isfinite(cosh_t[0]) || !std::isfinite(sinh_t[0])) return fail(EINVAL_, "set_checkerboard: diag_factor must be positive, cosh / sinh finite");
+    const int n = e->n; std::vector<std::vector<std::pair<int, int>>> groups(n_groups); size_t b = 0;
+    for (int g = 0; g < n_groups; ++g) {
+        if (group_sizes[g] < 0 || group_sizes[g] > n / 2) return fail(EINVAL_, "set_checkerboard: a group holds at most n_sites/2 bonds");
+        std::vector<char> used(n, 0);
+        for (int k = 0; k < group_sizes[g]; ++k, ++b) {
+            const int i = bonds[2 * b], j = bonds[2 * b + 1];
+            if (i < 0 || i >= n || j < 0 || j >= n || i == j) return fail(EINVAL_, "set_checkerboard: bond site out of range");
+            if (used[i] || used[j]) return fail(EINVAL_, "set_checkerboard: the bonds of one group must be disjoint");
+            used[i] = used[j] = 1; groups[g].push_back({i, j});
+        }
+    }
+    e->cb_groups.swap(groups); e->cb_c = cosh_t[0]; e->cb_s = sinh_t[0]; e->cb_f = diag_factor[0]; e->cb = true;
+    vecd I((size_t)n * n, 0.0); for (int i = 0; i < n; ++i) I[i + (size_t)n * i] = 1.0;
+    e->expK = I; e->cb_left(e->expK, false); e->invexpK = I; e->cb_left(e->invexpK, true);
+    for (auto& f : e->stack) f = LDR();
+    return OK;
 }
 void orc_destroy(orc_engine* e) { delete e; }
 int orc_set_fields(orc_engine* e, const int64_t* f) { for (int i = 0; i < e->n; ++i) for (int l = 0; l < e->nt; ++l) { const int64_t v = f[l + (size_t)e->nt * i]; if (v < 0 || v > 3) return fail(EINVAL_, "field value outside {0,1,2,3}"); e->fields[(size_t)l * e->n + i] = (int)v; } return OK; }
