@@ -50,7 +50,7 @@ ABI_SYMBOLS = [
     "measure_equal_time", "measure_accumulate", "measure_fetch",
     "sweep_unequal_time", "get_G_tau", "measure_unequal_time", "measure_unequal_fetch",
     "comm_unique_id", "comm_create_rccl", "comm_create_callbacks", "comm_destroy", "comm_rank", "comm_world_size",
-    "comm_transport", "comm_barrier", "comm_allreduce_sum", "partner_rank", "replica_exchange_round",
+    "comm_transport", "comm_barrier", "comm_allreduce_sum", "comm_selftest", "partner_rank", "replica_exchange_round",
 ]
 
 UNIQUE_ID_BYTES = 128
@@ -127,7 +127,7 @@ class DqmcLib:
             g("comm_destroy").argtypes = [C.c_void_p]; g("comm_destroy").restype = None
             g("comm_rank").argtypes = [C.c_void_p]; g("comm_world_size").argtypes = [C.c_void_p]
             g("comm_transport").argtypes = [C.c_void_p]; g("comm_transport").restype = C.c_char_p
-            g("comm_barrier").argtypes = [C.c_void_p]
+            g("comm_barrier").argtypes = [C.c_void_p]; g("comm_selftest").argtypes = [C.c_void_p]
             g("comm_allreduce_sum").argtypes = [C.c_void_p, c_double_p, C.c_int]
             g("partner_rank").argtypes = [C.c_int, C.c_int, C.c_int]
             g("replica_exchange_round").argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.POINTER(ExchangeResult)]
@@ -256,6 +256,10 @@ class Comm:
     @property
     def transport(self) -> str:
         return self.lib._sym("comm_transport")(self._h).decode()
+
+    def selftest(self):
+        """dqmc_comm_selftest: loop-back of the RCCL transport (every rank calls it)."""
+        self.lib.check(self.lib._sym("comm_selftest")(self._h))
 
     def barrier(self):
         self.lib.check(self.lib._sym("comm_barrier")(self._h))

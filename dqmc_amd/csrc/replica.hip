@@ -165,6 +165,38 @@ int dqmc_comm_allreduce_sum(dqmc_comm* c, double* x, int count) {
     }
     return 0;
 }
+// Loop-back check of a communicator's transport: the rank exchanges a pattern with ITSELF through the same grouped
+// send / receive path a round uses (ncclSend + ncclRecv to the own rank, or the callback), and, on RCCL, runs one
+// ncclAllReduce; the only way to exercise the RCCL code path on a machine with a single GPU.
+int dqmc_comm_selftest(dqmc_comm* c) {
+    if (!c) { set_error("comm_selftest: null communicator"); return DQMC_EINVAL; }
+    if (!c->rccl) { set_error("comm_selftest: RCCL transport only (a callback transport is checked by calling the callback)"); return DQMC_EINVAL; }
+    DQ_HIP(hipSetDevice(c->device));
+    const size_t bytes = 4096;
+    int8_t* a = nullptr; int8_t* b = nullptr;
+    DQ_HIP(hipMalloc(&a, bytes)); DQ_HIP(hipMalloc(&b, bytes));
+    std::vector<int8_t> h(bytes), g(bytes, 0);
+    for (size_t k = 0; k < bytes; ++k) h[k] = (int8_t)((k * 7 + c->rank) & 3);
+    int rc = 0;
+    do {
+        if (hipMemcpyAsync(a, h.data(), bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess || hipMemsetAsync(b, 0, bytes, c->stream) != hipSuccess) { set_error("comm_selftest: copy failed"); rc = DQMC_ENODEVICE; break; }
+        rc = p2p(c, a, b, bytes, c->rank, 0, c->stream); if (rc) break;
+        if (hipMemcpyAsync(g.data(), b, bytes, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { set_error("comm_selftest: copy back failed"); rc = DQMC_ENODEVICE; break; }
+        if (std::memcmp(h.data(), g.data(), bytes) != 0) { set_error("comm_selftest: loop-back data mismatch"); rc = DQMC_ENUMERIC; break; }
+        const double x[2] = {1.5 + c->rank, -2.0}; double y[2] = {0.0, 0.0};
+        rc = p2p_host(c, x, y, 2, c->rank, 1, c->stream); if (rc) break;
+        if (y[0] != x[0] || y[1] != x[1]) { set_error("comm_selftest: loop-back of two doubles mismatch"); rc = DQMC_ENUMERIC; break; }
+        double z[2] = {1.0, (double)c->rank};
+        if (hipMemcpyAsync(c->dbuf, z, sizeof(z), hipMemcpyHostToDevice, c->stream) != hipSuccess) { set_error("comm_selftest: copy failed"); rc = DQMC_ENODEVICE; break; }
+        ncclResult_t r = ncclAllReduce(c->dbuf, c->dbuf + 4, 2, ncclDouble, ncclSum, c->nc, c->stream);
+        if (r != ncclSuccess) { set_error(std::string("comm_selftest: ncclAllReduce: ") + ncclGetErrorString(r)); rc = DQMC_ENODEVICE; break; }
+        if (hipMemcpyAsync(z, c->dbuf + 4, sizeof(z), hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { set_error("comm_selftest: copy back failed"); rc = DQMC_ENODEVICE; break; }
+        const double want1 = 0.5 * c->world * (c->world - 1);
+        if (z[0] != (double)c->world || z[1] != want1) { set_error("comm_selftest: all-reduce result mismatch"); rc = DQMC_ENUMERIC; break; }
+    } while (false);
+    (void)hipFree(a); (void)hipFree(b);
+    return rc;
+}
 int dqmc_comm_barrier(dqmc_comm* c) { double z = 0.0; return dqmc_comm_allreduce_sum(c, &z, 1); }
 
 int dqmc_replica_exchange_round(dqmc_engine* e, dqmc_comm* c, int exchange_attempt, double u, dqmc_exchange_result* res) {

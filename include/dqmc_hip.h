@@ -278,6 +278,9 @@ int dqmc_comm_rank(dqmc_comm* c);
 int dqmc_comm_world_size(dqmc_comm* c);
 /* "rccl" or "callbacks" */
 const char* dqmc_comm_transport(dqmc_comm* c);
+/* Diagnostic: loop-back of the RCCL transport (grouped ncclSend / ncclRecv of a pattern to the own rank, two doubles
+ * the same way, one ncclAllReduce); every rank of the communicator must call it.  No counterpart in the reference.   */
+int dqmc_comm_selftest(dqmc_comm* c);
 /* MPI_Barrier (source/main.cpp:148) and the MPI_Reduce(SUM) of source/main.cpp:186-187
  * (every rank receives the sums).                                                          */
 int dqmc_comm_barrier(dqmc_comm* c);

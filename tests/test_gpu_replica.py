@@ -183,3 +183,34 @@ def test_driver_parallel_tempering_in_process(hip, tmp_path):
     env2 = dict(env, RANK="0", WORLD_SIZE="2", LOCAL_RANK="0")
     out = subprocess.run([driver, "parameters.in", "0", "4242"], cwd=tmp_path, capture_output=True, text=True, timeout=300, env=env2)
     assert out.returncode == 1 and "must match the number of MPI processes" in out.stderr
+
+
+@pytest.mark.parametrize("with_torch_nccl", [False, True])
+def test_rccl_transport_loopback_on_one_gpu(hip, with_torch_nccl):
+    """The RCCL transport on hardware as far as one GPU allows (RCCL refuses two ranks on one device): a world-1 communicator
+    from dqmc_comm_unique_id / dqmc_comm_create_rccl, then dqmc_comm_selftest = grouped ncclSend + ncclRecv to the own rank through
+    the same helper a round uses, and one ncclAllReduce.  Second case: in a process that has already brought up torch.distributed's
+    own "nccl" (= RCCL) process group, as bench.py --gpus N has when it creates the communicator.  Runs in a child process: a crash
+    inside the collective library must fail this test, not end the session."""
+    import sys
+    code = (
+        "import os, sys\n"
+        f"sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})\n"
+        "import numpy as np\n"
+        + ("import torch, torch.distributed as dist\n"
+           "os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29577', RANK='0', WORLD_SIZE='1')\n"
+           "torch.cuda.set_device(0); dist.init_process_group('nccl', rank=0, world_size=1)\n"
+           "t = torch.ones(4, device='cuda'); dist.all_reduce(t); torch.cuda.synchronize(); assert float(t.sum()) == 4.0\n" if with_torch_nccl else "")
+        + "import dqmc_amd\n"
+        "lib = dqmc_amd.lib()\n"
+        "uid = lib.comm_unique_id(); assert len(uid) == 128 and any(uid)\n"
+        "c = lib.comm_rccl(uid, 1, 0, 0)\n"
+        "assert c.transport == 'rccl' and c.rank == 0 and c.world == 1\n"
+        "c.selftest(); c.barrier(); assert float(c.allreduce_sum([2.5])[0]) == 2.5\n"
+        "m = dqmc_amd.HubbardModel(**dqmc_amd.CONFIGS['cfg1']); e = m.engine(lib); e.set_fields(m.random_fields(1)); e.init()\n"
+        "r = c.exchange_round(e, 1, 0.5); assert r.partner == -1 and r.accepted == 0      # a single replica has nobody to swap with\n"
+        "c.selftest(); c.close(); e.close()\n"
+        + ("dist.destroy_process_group()\n" if with_torch_nccl else "")
+        + "print('LOOPBACK OK')\n")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "LOOPBACK OK" in out.stdout, (out.returncode, out.stdout[-2000:], out.stderr[-4000:])
