@@ -235,6 +235,167 @@ __global__ __launch_bounds__(256) void gemm_tile64_kernel(GemmDesc g, int tiles_
     }
 }
 
+// ---- single-matrix variant for 256 < n <= 1024 (cfg 5: n = 576) ----
+// The split-K kernel above keeps a quarter of K per wave in registers (160 VGPRs of operands at n = 576): two workgroups
+// per CU, 1 296 workgroups = three rounds, each a full memory round trip with 80 eight-byte loads per lane -- 45 us for
+// 0.38 GFLOP.  Here a workgroup owns a 32x32 tile of C (one 16x16 MFMA tile per wave) and walks K in 32-deep stages through
+// LDS, so the two waves that share rows (columns) share the A (B) stage and the operand traffic halves; the global loads of the
+// next three stages sit in a register queue while a stage is multiplied.  ceil(n/32)^2 workgroups, all resident at once.
+// Measured at n = 576: 22.6 us (split-K 45.0).  What bounds it now is the operand volume through a CU's L1 (about 25 GB/s
+// per CU with every miss slot busy, whatever the queue depth -- 2, 3 and 5 stages time the same, and so do 64-deep stages and
+// two accumulator chains): 324 tiles on 256 CUs leave 68 CUs with two workgroups = 590 KB each.  A 48x32 tile (216 workgroups,
+// 369 KB per CU) would bring it to ~14 us; not built.
+// Workgroups are dealt to the 8 XCDs round-robin, so workgroup w takes tile (w % 8) * chunk + w / 8 of the column-major tile
+// list: an XCD's L2 serves all of A but only ~1/8 of B.  C leaves in 128-byte row segments from the accumulators and (when
+// asked for) C^T in 256-byte segments through LDS.
+//   * The queue's loads are inline asm and its waits explicit (s_waitcnt vmcnt(2 x loads per stage)): left to the compiler the
+//     wait in front of a stage's LDS write was vmcnt(0..7) on every path (the insertion pass merges the unrolled bodies'
+//     counters conservatively), one full memory round trip per stage.  Every iteration issues the same number of loads (past
+//     the end: a repeat of the last stage that is never used) so the count stays uniform, loaded values are touched only after
+//     the wait, and the queue is drained before the epilogue may reuse its registers.
+//   * The barriers order LDS only (s_waitcnt lgkmcnt(0); s_barrier): a __syncthreads() would wait for the whole queue.
+//   * LDS layouts are chosen so that neither side conflicts: an operand that arrives with consecutive lanes along k (B, and A
+//     when transposed) is kept [column][k] with a row pitch of 34 doubles (MFMA reads: slot 2 r + kk, a bijection per half
+//     wave), A otherwise [k][row] with pitch 48.
+//   * Addresses are base pointers per thread + stage * stride; only a partial last stage (n % 32 != 0) or an edge tile takes
+//     the clamped / masked path.
+__device__ __forceinline__ void lds_only_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+template <bool TRANSA, bool HAS_KS, int KS /* 32 or 64: depth of a stage */>
+__global__ __launch_bounds__(256) void gemm_stage32_kernel(GemmDesc g, int T, int chunk) {
+    constexpr int D = 3, NL = KS / 8, LPS = (HAS_KS ? 3 : 2) * NL, PK = KS + 2, PR = 48;
+    __shared__ double As[TRANSA ? 32 * PK : KS * PR];
+    __shared__ double Bs[32 * PK];
+    __shared__ double Ct[32][33];
+    const int chain = blockIdx.y;
+    const int w = blockIdx.x;
+    const int L = (w & 7) * chunk + (w >> 3);
+    if (L >= T * T) return;                                  // workgroup-uniform: the grid is rounded up to a multiple of 8
+    const int n = g.n;
+    const int i0 = (L % T) * 32, j0 = (L / T) * 32;
+    const double* __restrict__ A = g.A.at(chain);
+    const double* __restrict__ B = g.B.at(chain);
+    double* __restrict__ C = g.C.at(chain);
+    const double* __restrict__ ks = HAS_KS ? g.ks.at(chain) : nullptr;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int r = lane & 15, kk = lane >> 4;
+    const int wi = (wave & 1) * 16, wj = (wave >> 1) * 16;
+    // staging roles.  A: row rlo, k = rhi + 8 s;  A^T and B: k = klo, row / column khi + (256 / KS) s
+    const int rlo = t & 31, rhi = t >> 5;
+    const int klo = t & (KS - 1), khi = t / KS;
+    constexpr int XS = 256 / KS;
+    const int nst = (n + KS - 1) / KS;
+    const bool interior = i0 + 32 <= n && j0 + 32 <= n;
+    const bool ragged = (n % KS) != 0;
+    const double* pa[NL]; const double* pb[NL]; const double* pk[NL];
+#pragma unroll
+    for (int s = 0; s < NL; ++s) {
+        pa[s] = TRANSA ? A + klo + (long)n * min(i0 + khi + XS * s, n - 1) : A + min(i0 + rlo, n - 1) + (long)n * (rhi + 8 * s);
+        pb[s] = B + klo + (long)n * min(j0 + khi + XS * s, n - 1);
+        pk[s] = HAS_KS ? (TRANSA ? ks + klo : ks + rhi + 8 * s) : nullptr;
+    }
+    const long sa = TRANSA ? KS : (long)KS * n;                // doubles per stage
+    double qa[D][NL], qb[D][NL], qk[D][NL];
+#define DQ_GLOAD(dst, ptr) asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory")
+    auto load_stage = [&](int st, double (&a)[NL], double (&b)[NL], double (&kf)[NL]) {
+        if (ragged && st == nst - 1) {                        // partial last stage: clamp k (uniform branch, loads stay unconditional inside)
+#pragma unroll
+            for (int s = 0; s < NL; ++s) {
+                const int ka = min(KS * st + (TRANSA ? klo : rhi + 8 * s), n - 1), kb = min(KS * st + klo, n - 1);
+                const double* qpa = TRANSA ? A + ka + (long)n * min(i0 + khi + XS * s, n - 1) : A + min(i0 + rlo, n - 1) + (long)n * ka;
+                const double* qpb = B + kb + (long)n * min(j0 + khi + XS * s, n - 1);
+                DQ_GLOAD(a[s], qpa); DQ_GLOAD(b[s], qpb);
+                if (HAS_KS) { const double* qpk = ks + ka; DQ_GLOAD(kf[s], qpk); }
+            }
+            return;
+        }
+#pragma unroll
+        for (int s = 0; s < NL; ++s) {
+            const double* qpa = pa[s] + st * sa; const double* qpb = pb[s] + st * KS;
+            DQ_GLOAD(a[s], qpa); DQ_GLOAD(b[s], qpb);
+            if (HAS_KS) { const double* qpk = pk[s] + st * KS; DQ_GLOAD(kf[s], qpk); }
+        }
+    };
+#undef DQ_GLOAD
+    // ties the slot's registers to the wait: nothing may touch them before it
+    auto wait_stage = [&](double (&a)[NL], double (&b)[NL], double (&kf)[NL]) {
+#pragma unroll
+        for (int s = 0; s < NL; ++s) asm volatile("s_waitcnt vmcnt(%3)" : "+v"(a[s]), "+v"(b[s]), "+v"(kf[s]) : "n"((D - 1) * LPS) : "memory");
+    };
+    static_assert((D - 1) * LPS <= 63, "vmcnt is a 6-bit counter");
+    auto store_stage = [&](int st, const double (&a)[NL], const double (&b)[NL], const double (&kf)[NL]) {
+        const bool masked = !interior || (ragged && st == nst - 1);       // uniform
+#pragma unroll
+        for (int s = 0; s < NL; ++s) {
+            const int xk = rhi + 8 * s, xr = khi + XS * s;
+            double va = a[s], vb = b[s];
+            if (HAS_KS) va *= kf[s];
+            if (masked) {
+                const int k = KS * st + (TRANSA ? klo : xk), row = i0 + (TRANSA ? xr : rlo);
+                if (!(k < n && row < n)) va = 0.0;
+                if (!(KS * st + klo < n && j0 + xr < n)) vb = 0.0;
+            }
+            if (TRANSA) As[xr * PK + klo] = va; else As[xk * PR + rlo] = va;
+            Bs[xr * PK + klo] = vb;
+        }
+    };
+#pragma unroll
+    for (int u = 0; u < D; ++u) load_stage(min(u, nst - 1), qa[u], qb[u], qk[u]);
+    d4 acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};      // two chains: a dependent fp64 MFMA waits for its predecessor's full latency
+    for (int st0 = 0; st0 < nst; st0 += D) {
+#pragma unroll
+        for (int u = 0; u < D; ++u) {
+            const int st = st0 + u;
+            if (st < nst) {                                   // workgroup-uniform
+                wait_stage(qa[u], qb[u], qk[u]);
+                lds_only_barrier();                           // the previous stage has been read by every wave
+                store_stage(st, qa[u], qb[u], qk[u]);
+                load_stage(min(st + D, nst - 1), qa[u], qb[u], qk[u]);
+                lds_only_barrier();
+#pragma unroll
+                for (int q = 0; q < KS / 4; ++q) {
+                    const int k = 4 * q + kk;
+                    const double av = TRANSA ? As[(wi + r) * PK + k] : As[k * PR + wi + r];
+                    if (q & 1) acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(Bs[(wj + r) * PK + k], av, acc2, 0, 0, 0);
+                    else acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Bs[(wj + r) * PK + k], av, acc, 0, 0, 0);
+                }
+            }
+        }
+    }
+    // drain the queue: its registers may be reused from here on
+#pragma unroll
+    for (int u = 0; u < D; ++u)
+#pragma unroll
+        for (int s = 0; s < NL; ++s) asm volatile("s_waitcnt vmcnt(0)" : "+v"(qa[u][s]), "+v"(qb[u][s]), "+v"(qk[u][s]) :: "memory");
+    // lane holds C[i0 + wi + r][j0 + wj + kk + 4 reg]
+    const int i = i0 + wi + r;
+    const double rsv = (g.rs.p && i < n) ? g.rs.at(chain)[i] : 1.0;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        const int jl = wj + kk + 4 * reg, j = j0 + jl;
+        double v = (acc[reg] + acc2[reg]) * rsv;
+        if (i < n && j < n) {
+            if (g.cs.p) v *= g.cs.at(chain)[j];
+            double* dst = C + i + (long)n * j;
+            if (g.accumulate) v += *dst;
+            *dst = v;
+        }
+        Ct[wi + r][jl] = v;
+    }
+    if (g.CT.p) {
+        __syncthreads();
+        double* __restrict__ CT = g.CT.at(chain);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int il = rhi + 8 * s;                       // row of C = column of CT; rlo runs along j
+            if (i0 + il < n && j0 + rlo < n) CT[(j0 + rlo) + (long)n * (i0 + il)] = Ct[il][rlo];
+        }
+    }
+}
+
 template <int KQ>
 static void launch_splitk(const GemmDesc& g, int n_chains, hipStream_t s) {
     const int tiles = (g.n + 15) / 16;
@@ -261,6 +422,18 @@ static int launch_gemm_main(const GemmDesc& g, int n_chains, hipStream_t s, bool
         if (g.transA) hipLaunchKernelGGL((gemm_tile64_kernel<true>), grid, block, 0, s, g, tiles);
         else hipLaunchKernelGGL((gemm_tile64_kernel<false>), grid, block, 0, s, g, tiles);
         DQ_HIP(hipGetLastError());
+        return 0;
+    }
+    static const bool no_stage32 = getenv("DQMC_GEMM_NO_STAGE32") != nullptr;      // A/B switch
+    if (n >= 384 && !no_stage32) {                                                 // measured: 13.7 vs 10.9 us at n = 324, 15 vs 22 at 400, 31 vs 45 at 576
+        const int T = (n + 31) / 32, chunk = (T * T + 7) / 8;
+        dim3 grid(8 * chunk, n_chains), block(256);
+        // (64-deep stages measured no faster: 24.9 against 23.0 us at n = 576, with 250 VGPRs)
+#define DQ_ST(TA, KSC) hipLaunchKernelGGL((gemm_stage32_kernel<TA, KSC, 32>), grid, block, 0, s, g, T, chunk)
+        if (g.transA) { if (g.ks.p) DQ_ST(true, true); else DQ_ST(true, false); } else { if (g.ks.p) DQ_ST(false, true); else DQ_ST(false, false); }
+#undef DQ_ST
+        DQ_HIP(hipGetLastError());
+        *ct_done = true;
         return 0;
     }
     if (n <= 640) {
