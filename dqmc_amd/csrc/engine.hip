@@ -90,7 +90,8 @@ struct Ctx {
         // latency regime only: with many chains per launch the blocked LU + per-column substitution has the higher throughput
         // (128 chains, cfg 3: 458 ms per step against 483 ms with the single-wave panels)
         const int gj_max_chains = getenv("DQMC_GJ_MAX_CHAINS") ? atoi(getenv("DQMC_GJ_MAX_CHAINS")) : 8;
-        use_gj = n <= 256 && C <= gj_max_chains && getenv("DQMC_LU_CLASSIC") == nullptr;
+        const int gj_max_n = getenv("DQMC_GJ_MAX_N") ? atoi(getenv("DQMC_GJ_MAX_N")) : 640;      // A/B switch (256: blocked LU above; beyond 640 the 16-wave panel spills 12 VGPRs)
+        use_gj = n <= gj_max_n && n <= 1024 && C <= gj_max_chains && getenv("DQMC_LU_CLASSIC") == nullptr;
         DQ_HIP(hipMemsetAsync(ipool, 0, sizeof(int) * (3L * C * n + 4), stream));
         return 0;
     }

@@ -181,9 +181,9 @@ __global__ __launch_bounds__(64) void gj_panel_kernel(CMat Am, int* rowpos_p, lo
 // and its candidate lane publishes {key, lane} and the row's live part (columns >= J) into the wave's LDS slot BEFORE the global
 // winner is known; after the barrier every wave reads the W keys, picks the winner (largest |a|, lowest wave on ties) and reads the
 // pivot row from the winner's slot.  Slots are double-buffered on the parity of J (a wave can be at most one step ahead).
-template <int J>
+template <int J, int NW>
 __device__ __forceinline__ void gj_step_mw(double (&a)[GJ_NB], bool& live, int& mypos, int& myperm, bool& singular, int lane, int wave, int nw, int k0,
-                                           double (*slot_row)[4][GJ_NB + 2], unsigned long long (*slot_key)[4]) {
+                                           double (*slot_row)[NW][GJ_NB + 2], unsigned long long (*slot_key)[NW]) {
     constexpr int PAR = J & 1;
     constexpr int C0 = J & ~1;
     // every lane's reciprocal of its own candidate element, off the critical path (dgetf2 scales by the reciprocal pivot as
@@ -207,14 +207,18 @@ __device__ __forceinline__ void gj_step_mw(double (&a)[GJ_NB], bool& live, int& 
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    // all four keys in ONE LDS round trip (slots of absent waves stay 0 = "no candidate"): reading them under `w < nw` branches
+    // all keys in ONE LDS round trip (slots of absent waves stay 0 = "no candidate"): reading them under `w < nw` branches
     // made each key its own dependent round trip, ~450 clk per step
-    const ulonglong2 k01 = *reinterpret_cast<const ulonglong2*>(&slot_key[PAR][0]);
-    const ulonglong2 k23 = *reinterpret_cast<const ulonglong2*>(&slot_key[PAR][2]);
-    unsigned long long best = k01.x; int pw = 0;
-    if ((k01.y >> 8) > (best >> 8)) { best = k01.y; pw = 1; }
-    if ((k23.x >> 8) > (best >> 8)) { best = k23.x; pw = 2; }
-    if ((k23.y >> 8) > (best >> 8)) { best = k23.y; pw = 3; }
+    ulonglong2 kp[NW / 2];
+#pragma unroll
+    for (int q = 0; q < NW / 2; ++q) kp[q] = *reinterpret_cast<const ulonglong2*>(&slot_key[PAR][2 * q]);
+    unsigned long long best = kp[0].x; int pw = 0;
+    if ((kp[0].y >> 8) > (best >> 8)) { best = kp[0].y; pw = 1; }
+#pragma unroll
+    for (int q = 1; q < NW / 2; ++q) {                    // strict: the lowest wave wins a tie (= the lowest row, as dgetf2's idamax)
+        if ((kp[q].x >> 8) > (best >> 8)) { best = kp[q].x; pw = 2 * q; }
+        if ((kp[q].y >> 8) > (best >> 8)) { best = kp[q].y; pw = 2 * q + 1; }
+    }
     const int pl = (int)(best & 0xFFULL);
     double prow[GJ_NB - C0];
 #pragma unroll
@@ -230,25 +234,28 @@ __device__ __forceinline__ void gj_step_mw(double (&a)[GJ_NB], bool& live, int& 
 #pragma unroll
     for (int c = J + 1; c < GJ_NB; ++c) a[c] = fma(-l, prow[c - C0], a[c]);
 }
-template <int J>
+template <int J, int NW>
 struct GjStepsMW {
     static __device__ __forceinline__ void run(double (&a)[GJ_NB], bool& live, int& mypos, int& myperm, bool& singular, int lane, int wave, int nw, int nbw, int k0,
-                                               double (*slot_row)[4][GJ_NB + 2], unsigned long long (*slot_key)[4]) {
-        if (J < nbw) gj_step_mw<J>(a, live, mypos, myperm, singular, lane, wave, nw, k0, slot_row, slot_key);      // workgroup-uniform
-        GjStepsMW<J + 1>::run(a, live, mypos, myperm, singular, lane, wave, nw, nbw, k0, slot_row, slot_key);
+                                               double (*slot_row)[NW][GJ_NB + 2], unsigned long long (*slot_key)[NW]) {
+        if (J < nbw) gj_step_mw<J, NW>(a, live, mypos, myperm, singular, lane, wave, nw, k0, slot_row, slot_key);      // workgroup-uniform
+        GjStepsMW<J + 1, NW>::run(a, live, mypos, myperm, singular, lane, wave, nw, nbw, k0, slot_row, slot_key);
     }
 };
-template <>
-struct GjStepsMW<GJ_NB> {
-    static __device__ __forceinline__ void run(double (&)[GJ_NB], bool&, int&, int&, bool&, int, int, int, int, int, double (*)[4][GJ_NB + 2], unsigned long long (*)[4]) {}
+template <int NW>
+struct GjStepsMW<GJ_NB, NW> {
+    static __device__ __forceinline__ void run(double (&)[GJ_NB], bool&, int&, int&, bool&, int, int, int, int, int, double (*)[NW][GJ_NB + 2], unsigned long long (*)[NW]) {}
 };
+// NW: most waves the workgroup may have (one matrix row per lane): 4 for n <= 256, 10 for n <= 640, 16 for n <= 1024
+template <int NW>
 
-__global__ __launch_bounds__(256) void gj_panel_mw_kernel(CMat Am, int* rowpos_p, long rowpos_stride, int* perm_p, long perm_stride, double* tinv_p,
+__global__ __launch_bounds__(64 * NW) void gj_panel_mw_kernel(CMat Am, int* rowpos_p, long rowpos_stride, int* perm_p, long perm_stride, double* tinv_p,
                                                           double* logabsdet, int accumulate, int* info, int n, int k0) {
     __shared__ __attribute__((aligned(16))) double LU[GJ_NB][GJ_NB];
-    __shared__ __attribute__((aligned(16))) double slot_row[2][4][GJ_NB + 2];      // row | reciprocal of its pivot element
-    __shared__ __attribute__((aligned(16))) unsigned long long slot_key[2][4];
+    __shared__ __attribute__((aligned(16))) double slot_row[2][NW][GJ_NB + 2];     // row | reciprocal of its pivot element
+    __shared__ __attribute__((aligned(16))) unsigned long long slot_key[2][NW];
     __shared__ int s_sing;
+    static_assert(NW % 2 == 0, "keys are read in pairs");
     const int chain = blockIdx.y;
     const double* __restrict__ A = Am.at(chain);
     int* rowpos = rowpos_p + (long)chain * rowpos_stride;
@@ -264,10 +271,10 @@ __global__ __launch_bounds__(256) void gj_panel_mw_kernel(CMat Am, int* rowpos_p
     for (int c = 0; c < GJ_NB; ++c) a[c] = (live && c < nbw) ? A[r + (long)n * (k0 + c)] : 0.0;
     for (int e = t; e < GJ_NB * GJ_NB; e += blockDim.x) (&LU[0][0])[e] = ((e >> 5) == (e & 31)) ? 1.0 : 0.0;   // identity padding for nbw < 32
     if (t == 0) s_sing = 0;
-    if (t < 8) (&slot_key[0][0])[t] = 0ULL;               // waves that do not exist never publish: their keys stay "no candidate"
+    if (t < 2 * NW) (&slot_key[0][0])[t] = 0ULL;          // waves that do not exist never publish: their keys stay "no candidate"
     __syncthreads();
 
-    GjStepsMW<0>::run(a, live, mypos, myperm, singular, lane, wave, nw, nbw, k0, slot_row, slot_key);
+    GjStepsMW<0, NW>::run(a, live, mypos, myperm, singular, lane, wave, nw, nbw, k0, slot_row, slot_key);
 
     __syncthreads();                                     // identity fill done everywhere before the pivot rows overwrite theirs
     if (r < n) { if (k0 == 0) rowpos[r] = mypos; else if (mypos >= 0) rowpos[r] = mypos; }
@@ -441,11 +448,14 @@ __global__ __launch_bounds__(256) void gj_update_kernel(Mat Am, Mat Bm, Mat SAm,
 // perm / rowpos: n ints per chain.  logabsdet (optional) receives (+)= log|det A|; *info |= 1 on a zero / NaN pivot.
 int launch_gj_solve(Mat A, Mat B, Mat X, Mat SA, double* tinv, int* perm, long perm_stride, int* rowpos, long rowpos_stride,
                     double* logabsdet, int accumulate_logdet, int* info, int n, int n_chains, hipStream_t s) {
-    if (n > 256) { set_error("gj_solve supports n <= 256"); return -1; }
+    if (n > 1024) { set_error("gj_solve supports n <= 1024"); return -1; }
     for (int k0 = 0; k0 < n; k0 += GJ_NB) {
         const dim3 pg(1, n_chains);
         static const bool one_wave = getenv("DQMC_GJ_PANEL_1W") != nullptr;      // A/B switch: the single-wave panel
-        if (!one_wave && n > 64) hipLaunchKernelGGL(gj_panel_mw_kernel, pg, dim3(((n + 63) / 64) * 64), 0, s, CMat(A), rowpos, rowpos_stride, perm, perm_stride, tinv, logabsdet, accumulate_logdet, info, n, k0);
+        const dim3 pb(((n + 63) / 64) * 64);
+        if (n > 640) hipLaunchKernelGGL((gj_panel_mw_kernel<16>), pg, pb, 0, s, CMat(A), rowpos, rowpos_stride, perm, perm_stride, tinv, logabsdet, accumulate_logdet, info, n, k0);
+        else if (n > 256) hipLaunchKernelGGL((gj_panel_mw_kernel<10>), pg, pb, 0, s, CMat(A), rowpos, rowpos_stride, perm, perm_stride, tinv, logabsdet, accumulate_logdet, info, n, k0);
+        else if (!one_wave && n > 64) hipLaunchKernelGGL((gj_panel_mw_kernel<4>), pg, pb, 0, s, CMat(A), rowpos, rowpos_stride, perm, perm_stride, tinv, logabsdet, accumulate_logdet, info, n, k0);
         else if (n <= 64) hipLaunchKernelGGL((gj_panel_kernel<1>), pg, dim3(64), 0, s, CMat(A), rowpos, rowpos_stride, perm, perm_stride, tinv, logabsdet, accumulate_logdet, info, n, k0);
         else if (n <= 128) hipLaunchKernelGGL((gj_panel_kernel<2>), pg, dim3(64), 0, s, CMat(A), rowpos, rowpos_stride, perm, perm_stride, tinv, logabsdet, accumulate_logdet, info, n, k0);
         else hipLaunchKernelGGL((gj_panel_kernel<4>), pg, dim3(64), 0, s, CMat(A), rowpos, rowpos_stride, perm, perm_stride, tinv, logabsdet, accumulate_logdet, info, n, k0);
