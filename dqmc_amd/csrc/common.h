@@ -129,6 +129,11 @@ int launch_lu(Mat A, int* perm, long perm_stride, double* logabsdet, int accumul
 //           triangular back substitution (no factorisation needed).
 int launch_lu_solve(CMat LU, const int* perm, long perm_stride, Mat X, CVec dg, int mode, int n, int n_chains, hipStream_t s);
 
+// ---- tri_solve.hip ------------------------------------------------------------
+// X = R^-1 diag(dg) for the permuted-triangular R of one to_LDR (perm = its jpvt), n <= 640: blocked back substitution on
+// the matrix cores (n/16 dependent steps instead of n).  scratch: 16 * (n + 16) doubles per chain (inverses of the diagonal blocks).
+int launch_tri_solve(CMat R, const int* perm, long perm_stride, Mat X, CVec dg, double* scratch, long scratch_stride, int n, int n_chains, hipStream_t s);
+
 // ---- lu_gj.hip ----------------------------------------------------------------
 // X = A^-1 B for n <= 256 by blocked Gauss-Jordan elimination with partial pivoting (no substitution phase); A and B
 // are destroyed.  SA: n*n scratch per chain, tinv: 2048 doubles per chain, perm / rowpos: n ints per chain.

@@ -64,6 +64,8 @@ struct Ctx {
     unsigned long long* qsync = nullptr;       // cooperative QRCP records
     int* qabort = nullptr;                     // cooperative QRCP abort words: C
     double* tinv = nullptr;                    // Gauss-Jordan panel inverses: 2048 * C
+    double* trinv = nullptr;                   // blocked triangular solve: inverses of the 16 x 16 diagonal blocks, 16 * (n + 16) * C
+    bool use_tri = false;                      // R^-1 D by tri_solve.hip (n <= 640, few chains; DQMC_TRI_CLASSIC=1 keeps the per-column substitution)
     bool use_gj = false;                       // n <= 256, few chains: solves go through lu_gj.hip (DQMC_LU_CLASSIC=1 keeps dgetrf + dgetrs)
 
     Mat T(int k) const { return Mat{pool + (long)k * C * nn, nn}; }
@@ -87,6 +89,8 @@ struct Ctx {
         DQ_HIP(hipMalloc(&qsync, sizeof(unsigned long long) * qrcp_coop_sync_granules(n) * C));
         DQ_HIP(hipMalloc(&qabort, sizeof(int) * C));
         DQ_HIP(hipMalloc(&tinv, sizeof(double) * 2048 * C));
+        DQ_HIP(hipMalloc(&trinv, sizeof(double) * 16 * (n + 16) * C));
+        use_tri = n <= 640 && C <= 8 && getenv("DQMC_TRI_CLASSIC") == nullptr;
         // latency regime only: with many chains per launch the blocked LU + per-column substitution has the higher throughput
         // (128 chains, cfg 3: 458 ms per step against 483 ms with the single-wave panels)
         const int gj_max_chains = getenv("DQMC_GJ_MAX_CHAINS") ? atoi(getenv("DQMC_GJ_MAX_CHAINS")) : 8;
@@ -103,6 +107,7 @@ struct Ctx {
         if (qsync) (void)hipFree(qsync);
         if (qabort) (void)hipFree(qabort);
         if (tinv) (void)hipFree(tinv);
+        if (trinv) (void)hipFree(trinv);
         if (stream) (void)hipStreamDestroy(stream);
     }
 
@@ -122,7 +127,10 @@ struct Ctx {
     }
     // X = F.R^-1 diag(dinv): permuted triangular solve when F.R is a single QR factor, LU otherwise
     int r_inverse_scaled(LdrRef F, CVec dinv, Mat X, Mat lu_scratch) {
-        if (F.tri && *F.tri && F.jpvt) return launch_lu_solve(F.R, F.jpvt, n, X, dinv, 2, n, C, stream);
+        if (F.tri && *F.tri && F.jpvt) {
+            if (use_tri) return launch_tri_solve(F.R, F.jpvt, n, X, dinv, trinv, 16L * (n + 16), n, C, stream);
+            return launch_lu_solve(F.R, F.jpvt, n, X, dinv, 2, n, C, stream);
+        }
         DQ_TRY(launch_copy(F.R, lu_scratch, nn, C, stream));
         DQ_TRY(launch_lu(lu_scratch, lperm(), n, nullptr, 0, info(), n, C, stream, rowpos(), n));
         return launch_lu_solve(lu_scratch, lperm(), n, X, dinv, 1, n, C, stream);

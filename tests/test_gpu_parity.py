@@ -390,7 +390,7 @@ def test_alternative_kernel_paths_in_subprocess(hip):
         assert out.returncode == 0, (env_extra, out.stderr[-2000:])
         return json.loads(out.stdout.strip().splitlines()[-1])
     for env in ({}, {"DQMC_WALK_SUBMATRIX": "1"}, {"DQMC_SLICE_MULTIKERNEL": "1"}, {"DQMC_SLICE_PAIRS": "1"}, {"DQMC_SLICE_SOLO": "1"}, {"DQMC_LU_CLASSIC": "1"},
-                {"DQMC_GJ_PANEL_1W": "1"}, {"DQMC_QR_STREAMING": "1"}, {"DQMC_FORMQ_CLASSIC": "1"}, {"DQMC_INIT_SEQUENTIAL": "1"}):
+                {"DQMC_GJ_PANEL_1W": "1"}, {"DQMC_QR_STREAMING": "1"}, {"DQMC_FORMQ_CLASSIC": "1"}, {"DQMC_INIT_SEQUENTIAL": "1"}, {"DQMC_TRI_CLASSIC": "1"}):
         got = run(env)
         print(env, {k: (v["d0"], v["dA"]) if "d0" in v else v["dA"] for k, v in got.items()})
         for name in ("cfg2_therm", "cfg3_therm"):
