@@ -205,18 +205,21 @@ __global__ __launch_bounds__(256) void formq_kernel(CMat Am, const double* tau_p
         const int ic = ii > 0 ? ii : 0;                      // clamped: harmless reload past the end
         const long cb = (long)n * s_jpvt[ic]; tq[slot] = s_tau[ic];
 #pragma unroll
-        for (int j = 0; j < NRR; ++j) { const int r = 16 * j + rg; const double x = A[min(r, n - 1) + cb]; vq[slot][j] = (r > ic && r < n) ? x : (r == ic ? 1.0 : 0.0); }
+        for (int j = 0; j < NRR; ++j) vq[slot][j] = A[min(16 * j + rg, n - 1) + cb];      // raw: masked where it is used (see FormQBlock::fetch)
     };
     auto apply = [&](int slot, int i) {
         const double ti = tq[slot];
         if (ti == 0.0) return;
+        double v[NRR];
+#pragma unroll
+        for (int j = 0; j < NRR; ++j) { const int r = 16 * j + rg; v[j] = (r > i && r < n) ? vq[slot][j] : (r == i ? 1.0 : 0.0); }
         double s = 0.0;
 #pragma unroll
-        for (int j = 0; j < NRR; ++j) s += vq[slot][j] * q[j];
+        for (int j = 0; j < NRR; ++j) s += v[j] * q[j];
         s = row16_sum(s) * ti;
         if (c < i) s = 0.0;                                  // column still e_c: untouched by H_i
 #pragma unroll
-        for (int j = 0; j < NRR; ++j) q[j] -= s * vq[slot][j];
+        for (int j = 0; j < NRR; ++j) q[j] -= s * v[j];
     };
     fetch(0, cw_max); fetch(1, cw_max - 1); fetch(2, cw_max - 2);
     int i = cw_max;
@@ -242,26 +245,28 @@ __global__ __launch_bounds__(256) void formq_kernel(CMat Am, const double* tau_p
 template <int NRR, int M>
 struct FormQBlock {
     static constexpr int J0 = M > 0 ? M - 1 : 0;
+    // raw loads only: a select on a value just loaded makes the wave wait for that load inside the fetch, i.e. one memory latency per
+    // reflector whatever the depth of the ring (measured: 77 us per 256 x 256 form-Q with the mask here); the
+    // "rows <= i hold R, row i is the implicit 1" mask is applied where the value is used
     static __device__ __forceinline__ void fetch(double (&v)[NRR], double& t, const double* __restrict__ A, const int* s_jpvt, const double* s_tau,
                                                  int n, int rg, int ii) {
         const int ic = ii > 0 ? ii : 0;                      // clamped: harmless reload past the end
         const long cb = (long)n * s_jpvt[ic]; t = s_tau[ic];
 #pragma unroll
-        for (int j = J0; j < NRR; ++j) {
-            const int r = 16 * j + rg;
-            const double x = A[r + cb];
-            v[j] = (j > M) ? x : ((r > ic) ? x : (r == ic ? 1.0 : 0.0));
-        }
+        for (int j = J0; j < NRR; ++j) v[j] = A[16 * j + rg + cb];
     }
-    static __device__ __forceinline__ void apply(double (&q)[NRR], const double (&v)[NRR], double ti, int c, int i) {
+    static __device__ __forceinline__ void apply(double (&q)[NRR], const double (&v)[NRR], double ti, int c, int i, int rg) {
         if (ti == 0.0) return;
-        double s0 = 0.0, s1 = 0.0;
+        const int rm = 16 * M + rg;                          // row group M is the only one of j >= M that reaches up to row i
+        const double vm = (rm > i) ? v[M] : (rm == i ? 1.0 : 0.0);
+        double s0 = vm * q[M], s1 = 0.0;
 #pragma unroll
-        for (int j = M; j < NRR; ++j) { if ((j - M) & 1) s1 = fma(v[j], q[j], s1); else s0 = fma(v[j], q[j], s0); }
+        for (int j = M + 1; j < NRR; ++j) { if ((j - M) & 1) s1 = fma(v[j], q[j], s1); else s0 = fma(v[j], q[j], s0); }
         double s = row16_sum(s0 + s1) * ti;
         if (c < i) s = 0.0;                                  // column still e_c: untouched by H_i
+        q[M] = fma(-s, vm, q[M]);
 #pragma unroll
-        for (int j = M; j < NRR; ++j) q[j] = fma(-s, v[j], q[j]);
+        for (int j = M + 1; j < NRR; ++j) q[j] = fma(-s, v[j], q[j]);
     }
     static __device__ __forceinline__ void run(double (&q)[NRR], double (&vq)[4][NRR], double (&tq)[4], const double* __restrict__ A, const int* s_jpvt,
                                                const double* s_tau, int n, int rg, int c, int cw_max) {
@@ -275,7 +280,7 @@ struct FormQBlock {
             for (int top = hi; top >= 16 * M; top -= 4) {    // (hi + 1) is a multiple of 4: whole groups
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    apply(q, vq[e], tq[e], c, top - e);
+                    apply(q, vq[e], tq[e], c, top - e, rg);
                     fetch(vq[e], tq[e], A, s_jpvt, s_tau, n, rg, top - e - 4);
                 }
             }
