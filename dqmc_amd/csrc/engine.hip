@@ -253,6 +253,7 @@ struct Engine {
     long long meas_count = 0;                                    // measurements accumulated in meas_sum
     char* slice_sync = nullptr;                                  // [C][1 KiB] hand-off words of the persistent slice kernels
     bool persistent = false;                                     // holds a CU reservation for the single-launch slice kernel (slice_reserve)
+    bool handoff_failed = false;                                 // a hand-off of a persistent kernel timed out once: this engine stays on the kernel pairs from then on
     bool counted = false;                                        // registered in the per-device engine count (slice_engine_created)
     int* acc = nullptr;                                          // [C][nt]
     double* err = nullptr;                                       // [C][n_stack]
@@ -487,7 +488,7 @@ struct Engine {
     UpdateDesc udesc() const {
         UpdateDesc d; d.G = mG(); d.fields = fields; d.f_stride = (long)nt * n; d.expv = expv; d.invexpv = invexpv; d.v_stride = (long)nt * n;
         d.tabs = tabs; d.perm = rs_perm; d.kprop = rs_k; d.u = rs_u; d.rs_stride = (long)nt * n; d.Upanel = Upanel; d.Wpanel = Wpanel; d.Cpanel = Cpanel;
-        d.panel_stride = (long)UPDATE_KD * n; d.state = state; d.state_stride = 4; d.prep = prep; d.prep_stride = 4L * n; d.slice_sync = (persistent && slice_persistent_allowed(device)) ? slice_sync : nullptr; d.GT = Mat{GT, nn}; d.gt_valid = gt_valid ? 1 : 0; d.info = ctx.info(); d.acc_out = acc; d.acc_stride = nt; d.n = n; d.nt = nt;
+        d.panel_stride = (long)UPDATE_KD * n; d.state = state; d.state_stride = 4; d.prep = prep; d.prep_stride = 4L * n; d.slice_sync = (persistent && !handoff_failed && slice_persistent_allowed(device)) ? slice_sync : nullptr; d.GT = Mat{GT, nn}; d.gt_valid = gt_valid ? 1 : 0; d.info = ctx.info(); d.acc_out = acc; d.acc_stride = nt; d.n = n; d.nt = nt;
         return d;
     }
     int local_update(int l) {
@@ -629,7 +630,7 @@ struct Engine {
         }
         int h_info = 0;
         DQ_HIP(hipMemcpy(&h_info, ctx.info(), sizeof(int), hipMemcpyDeviceToHost));
-        if (h_info & 4) { set_error("persistent slice kernel: a hand-off timed out (workgroups not co-resident?)"); (void)hipMemset(ctx.info(), 0, sizeof(int)); (void)hipMemset(slice_sync, 0, (size_t)C * 1024); return DQMC_ENUMERIC; }
+        if (h_info & 4) { handoff_failed = true; set_error("persistent slice kernel: a hand-off timed out (workgroups not co-resident?); the chain state is undefined -- set the fields again and call dqmc_init; this engine uses the scan / flush kernel pairs from now on"); (void)hipMemset(ctx.info(), 0, sizeof(int)); (void)hipMemset(slice_sync, 0, (size_t)C * 1024); return DQMC_ENUMERIC; }
         if (h_info & 2) { set_error("cooperative QRCP gave up waiting for a partner workgroup (not co-resident?)"); (void)hipMemset(ctx.info(), 0, sizeof(int)); return DQMC_ENUMERIC; }
         if (h_info) { set_error("LU factorisation hit a zero or NaN pivot"); (void)hipMemset(ctx.info(), 0, sizeof(int)); return DQMC_ENUMERIC; }
         return 0;
