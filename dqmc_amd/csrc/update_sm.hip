@@ -406,7 +406,8 @@ __global__ __launch_bounds__(256) void slice_sm_kernel(UpdateDesc d, SliceSync* 
             if (final) break;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains before the arrival is signalled
             __syncthreads();
-            if (t == 0) __hip_atomic_fetch_add(&sy->arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // arrival: this workgroup's own word (a read-modify-write on one shared counter serialises in L2: 162 of them per window at n = 576)
+            if (t == 0) __hip_atomic_store(&sy->arrive[blockIdx.x - 1], win, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     } else {
         // ================= walk role =================
@@ -444,7 +445,15 @@ __global__ __launch_bounds__(256) void slice_sm_kernel(UpdateDesc d, SliceSync* 
             // wait until every flush workgroup has absorbed this window, then refresh the diagonal from the flushed G
             if (wave == 0) {
                 unsigned spins = 0;
-                while (__hip_atomic_load(&sy->arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)F * win) {
+                for (;;) {                                            // lane f, f + 64, f + 128 <-> flush workgroups (F <= 192): coalesced loads, no atomics
+                    bool all_in = true;
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        const int f = lane + 64 * q;
+                        const unsigned a = f < F ? __hip_atomic_load(&sy->arrive[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : win;
+                        all_in = all_in && a == win;
+                    }
+                    if (__all(all_in)) break;
                     if (++spins > SM_SPIN_LIMIT) { broken = true; break; }
                     __builtin_amdgcn_s_sleep(1);
                 }
@@ -467,6 +476,7 @@ __global__ __launch_bounds__(256) void slice_sm_kernel(UpdateDesc d, SliceSync* 
         if (ticket == (unsigned)F) {
             __hip_atomic_store(&sy->seq, 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&sy->arrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int f = 0; f < F; ++f) __hip_atomic_store(&sy->arrive[f], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&sy->exits, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
