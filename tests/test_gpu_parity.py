@@ -400,6 +400,35 @@ def test_alternative_kernel_paths_in_subprocess(hip):
         assert got["batched"]["fields"] and got["batched"]["dA"] <= TOL * got["batched"]["sA"], (env, got["batched"])
 
 
+def test_alternative_kernel_paths_above_256_in_subprocess(hip):
+    """The switches that only matter above N = 256 (split-K instead of the LDS-staged GEMM, blocked LU + substitution instead of the
+    Gauss-Jordan solve, per-column instead of blocked triangular solve, streaming instead of cooperative QRCP, kernel pairs instead of
+    the persistent sub-matrix slice kernel) at 24x24 and 20x20: same HS fields and accepted counts as the default path of this
+    process, G after initialisation and after a half sweep to 1e-9 of its largest entry (other summation orders)."""
+    import subprocess, sys, json, tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    def body(L):
+        m = HubbardModel(L1=L, L2=L, U=4.0, beta=1.0, nt=10, n_stab=5); f = m.random_fields(5); st = m.random_stream(np.random.default_rng(6))
+        e = m.engine(hip); e.set_fields(f); e.init(); G0 = e.get_G(); e.sweep_0_to_beta(*st)
+        return G0, e.get_G(), e.get_fields(), e.stats().n_accepted
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); import dqmc_amd; from dqmc_amd import HubbardModel\n"
+            "for L in (24, 20):\n"
+            "    m = HubbardModel(L1=L, L2=L, U=4.0, beta=1.0, nt=10, n_stab=5); f = m.random_fields(5); st = m.random_stream(np.random.default_rng(6))\n"
+            "    e = m.engine(dqmc_amd.lib()); e.set_fields(f); e.init(); G0 = e.get_G(); e.sweep_0_to_beta(*st)\n"
+            "    np.savez(sys.argv[1] + str(L) + '.npz', G0=G0, G1=e.get_G(), f=e.get_fields(), acc=e.stats().n_accepted)\n") % root
+    ref = {L: body(L) for L in (24, 20)}
+    for env in ({"DQMC_GEMM_NO_STAGE32": "1"}, {"DQMC_GJ_MAX_N": "256"}, {"DQMC_TRI_CLASSIC": "1"}, {"DQMC_QR_STREAMING": "1"}, {"DQMC_SLICE_MULTIKERNEL": "1"}):
+        with tempfile.TemporaryDirectory() as td:
+            e2 = dict(os.environ); e2.update(env)
+            out = subprocess.run([sys.executable, "-c", code, os.path.join(td, "r")], env=e2, capture_output=True, text=True, timeout=600)
+            assert out.returncode == 0, (env, out.stderr[-2000:])
+            for L in (24, 20):
+                z = np.load(os.path.join(td, f"r{L}.npz")); G0, G1, f1, acc = ref[L]
+                assert np.array_equal(z["f"], f1) and int(z["acc"]) == acc, (env, L)
+                assert np.abs(z["G0"] - G0).max() <= 1e-9 * max(1.0, np.abs(G0).max()), (env, L)
+                assert np.abs(z["G1"] - G1).max() <= 1e-9 * max(1.0, np.abs(G1).max()), (env, L)
+
+
 # ---- SURVEY.md 8(f) row 1: equal-time observables on the device ------------------------------------------------------
 @pytest.mark.parametrize("shape", [(4, 4, 4.0, 2.0, 20), (8, 8, 4.0, 4.0, 80), (6, 4, 4.0, 3.0, 30), (16, 16, 8.0, 8.0, 200)])
 def test_observables_parity(hip, orc, shape):
