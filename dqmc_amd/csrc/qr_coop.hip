@@ -62,6 +62,18 @@ __device__ __forceinline__ bool wave_argmax_norm(double nrm, int col, bool valid
     return top != 0ULL;
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a release fence = s_waitcnt vmcnt(0): inside the step
+// loop that makes a workgroup wait for its own global stores -- the published payload, and for the step's winner the reflector
+// column it records (up to n stores issued just before the barrier, a full memory latency) -- although every barrier of the
+// loop only protects LDS buffers; data for other workgroups travels as tagged granules and needs no fence.  (Measured at N = 576:
+// no difference, 4.5 ms per factorisation either way -- the polls that follow wait for those stores anyway; kept because it is
+// the weaker and sufficient barrier.)
+__device__ __forceinline__ void qc_lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 }  // namespace
 
 // grid = (P, chains); sync: [chains][2][P][qc_rec_granules(n)] granules (zeroed before launch); abort_word: 1 int per chain
@@ -151,7 +163,7 @@ __global__ __launch_bounds__(QC_T) void qrcp_coop_kernel(Mat Am, QrWork w, int n
                 scal[0] = tau_l; scal[1] = beta_l; scal[2] = scale_l;
             }
         }
-        __syncthreads();
+        qc_lds_barrier();
         // ---- [3] publish {norm, column, tau, beta, v} as tagged granules ----
         const int r_lo = (i / QC_T) * QC_T;                  // v is zero above row i and nobody reads rows below block jb: skip whole chunks
         for (int r = r_lo + t; r < n; r += QC_T) {
@@ -216,7 +228,7 @@ __global__ __launch_bounds__(QC_T) void qrcp_coop_kernel(Mat Am, QrWork w, int n
             if (t == 0) { tau[i] = tau_i; jpvt[i] = p; pposl[p & 31] = i; }
             wlive &= ~(1u << (p & 31));
         }
-        __syncthreads();
+        qc_lds_barrier();
         // ---- [6] apply H to my live columns ----
         const bool live0 = (wlive >> lc0) & 1u, live1 = (wlive >> (lc0 + 1)) & 1u;
         {
@@ -235,7 +247,7 @@ __global__ __launch_bounds__(QC_T) void qrcp_coop_kernel(Mat Am, QrWork w, int n
         }
         // ---- [7] norm down-date (dlaqp2): lane q < 32 of every wave owns local column q ----
         if (rg == (i & 15)) { rowi[lc0] = a[0][0]; rowi[lc0 + 1] = a[1][0]; }
-        __syncthreads();
+        qc_lds_barrier();
         int need_col = 0;
         if (lane < 32 && ((wlive >> lane) & 1u) && nrm1 != 0.0) {
             double temp = fabs(rowi[lane]) / nrm1; temp = fmax(0.0, 1.0 - temp * temp);
@@ -252,9 +264,9 @@ __global__ __launch_bounds__(QC_T) void qrcp_coop_kernel(Mat Am, QrWork w, int n
             }
             t0 = row16_sum(t0); t1 = row16_sum(t1);
             if (rg == 0) { tails[lc0] = t0; tails[lc0 + 1] = t1; }
-            __syncthreads();
+            qc_lds_barrier();
             if (lane < 32 && ((needmask >> lane) & 1u)) { nrm1 = (i + 1 < n) ? sqrt(tails[lane]) : 0.0; nrm2 = nrm1; }
-            __syncthreads();
+            qc_lds_barrier();
         }
         // ---- [8] every 16 steps (and at the end): row block jb is final -> store it as R0, shift the registers ----
         if ((i & 15) == 15 || i == n - 1) {
