@@ -123,15 +123,27 @@ __global__ __launch_bounds__(QC_T) void qrcp_coop_kernel(Mat Am, QrWork w, int n
         __syncthreads();
     }
 
+    // ---- [1] my best live column (identical in all four waves: same inputs, no exchange) and its header {norm, column}.  The header
+    // of step i + 1 is published as soon as the norms of step i are final -- before the reflector of step i + 1 is built and its
+    // payload written -- so that the exchange of the headers (one store + one load latency across the chip) runs while every
+    // workgroup builds its candidate: by the time a workgroup polls, the headers are usually there, and the step's critical path
+    // is payload store -> payload load instead of header store -> header load -> payload load.
+    int cbest = 0; bool have = false; int cstar = 0; double mynorm = 0.0;
+    auto pick_and_announce = [&](int step) {
+        have = wave_argmax_norm(nrm1, QC_COLS * wg + lane, lane < 32 && ((wlive >> lane) & 1u), cbest);
+        cstar = have ? cbest - QC_COLS * wg : 0;                                        // local column 0..31
+        mynorm = readlane_f64(nrm1, cstar);
+        if (t == 0) {
+            u64* rec = sync + ((long)(step & 1) * P + wg) * REC;
+            put_f64(rec, 0, have ? mynorm : -1.0, (unsigned)step + 1u);
+            put_f64(rec, 1, have ? (double)cbest : -1.0, (unsigned)step + 1u);
+        }
+    };
+    pick_and_announce(0);
     for (int i = 0; i < n; ++i) {
         const int jb = i >> 4, nj = NB - jb;            // slot j <-> row block jb + j
         const unsigned tag = (unsigned)i + 1u;
         u64* myrec = sync + ((long)(i & 1) * P + wg) * REC;
-        // ---- [1] my best live column (identical in all four waves: same inputs, no exchange) ----
-        int cbest = 0;
-        const bool have = wave_argmax_norm(nrm1, QC_COLS * wg + lane, lane < 32 && ((wlive >> lane) & 1u), cbest);
-        const int cstar = have ? cbest - QC_COLS * wg : 0;                              // local column 0..31
-        const double mynorm = readlane_f64(nrm1, cstar);
         // ---- [2] its Householder reflector, built speculatively ----
         if (wave == (cstar >> 3)) {
             const bool mine = cl == ((cstar & 7) >> 1);
@@ -172,8 +184,6 @@ __global__ __launch_bounds__(QC_T) void qrcp_coop_kernel(Mat Am, QrWork w, int n
             put_f64(myrec, QC_HDR + r, vmine, tag);
         }
         if (t == 0) {
-            put_f64(myrec, 0, have ? mynorm : -1.0, tag);
-            put_f64(myrec, 1, have ? (double)cbest : -1.0, tag);
             put_f64(myrec, 2, have ? scal[0] : 0.0, tag);
             put_f64(myrec, 3, have ? scal[1] : 0.0, tag);
         }
@@ -268,6 +278,8 @@ __global__ __launch_bounds__(QC_T) void qrcp_coop_kernel(Mat Am, QrWork w, int n
             if (lane < 32 && ((needmask >> lane) & 1u)) { nrm1 = (i + 1 < n) ? sqrt(tails[lane]) : 0.0; nrm2 = nrm1; }
             qc_lds_barrier();
         }
+        // ---- [1'] the norms are final: candidate and header of the next step ----
+        if (i + 1 < n) pick_and_announce(i + 1);
         // ---- [8] every 16 steps (and at the end): row block jb is final -> store it as R0, shift the registers ----
         if ((i & 15) == 15 || i == n - 1) {
             const int r = 16 * jb + rg;
