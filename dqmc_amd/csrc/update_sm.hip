@@ -181,8 +181,15 @@ struct SmProf { unsigned long long t_pass = 0, t_acc = 0, t_dump = 0, t_hand = 0
 template <int NS>
 __device__ __forceinline__ int sm_walk_window(const SmShared& sh, int& pos, int n, int kd, int t, const double* __restrict__ G,
                                               const double* __restrict__ GT, const UpdateDesc& d, long slice_off, int chain, int8_t* fields_g,
-                                              double* __restrict__ Ap, double* __restrict__ Bp, double* __restrict__ Cp SM_PROF_ARG) {
+                                              double* __restrict__ Ap, double* __restrict__ Bp, double* __restrict__ Cp, bool reload_diag SM_PROF_ARG) {
     const int lane = t & 63, wave = t >> 6, h = lane >> 5, m = lane & 31, r16 = lane & 15;
+    // after a flush the diagonal restarts from memory: its loads are issued first and reach LDS only after the first prefetch sets
+    // have been requested as well, so that the two round trips overlap (they used to follow each other: 1.2 us per window)
+    double dgl[NS];
+    if (reload_diag) {
+#pragma unroll
+        for (int s_ = 0; s_ < NS; ++s_) { const int tt = min(t + 256 * s_, n - 1); dgl[s_] = ld_coh(G + tt + (long)n * tt); }
+    }
     SMX(unsigned long long tw0; SMT(tw0))
     double c0[16], c1[16], t0[16], t1[16];                        // C[m][0..15], C[m][16..31], C^T[m][0..15], C^T[m][16..31] (static indices only: registers)
     SM_DECL8(pcA); SM_DECL8(prA); SM_DECL8(pcB); SM_DECL8(prB); SM_DECL8(pcC); SM_DECL8(prC);   // prefetched G column / row elements of group (g % 3)
@@ -205,6 +212,11 @@ __device__ __forceinline__ int sm_walk_window(const SmShared& sh, int& pos, int 
         }
     } else {
         if (g % 2 == 0) { SM_LOAD8(pcA, prA, g) } else { SM_LOAD8(pcB, prB, g) }
+    }
+    if (reload_diag) {                                            // workgroup-uniform
+#pragma unroll
+        for (int s_ = 0; s_ < NS; ++s_) { const int tt = t + 256 * s_; if (tt < n) sh.diag0[tt] = dgl[s_]; }
+        lds_barrier();
     }
 #define SM_GROUP(PCS, PRS, PCT, PRT)                                                                                                     \
     {                                                                                                                                    \
@@ -433,7 +445,7 @@ __global__ __launch_bounds__(256) void slice_sm_kernel(UpdateDesc d, SliceSync* 
         bool broken = false;
         SMX(SmProf prof; unsigned long long tk0, t_hand = 0; SMT(tk0))
         for (unsigned win = 1;; ++win) {
-            const int k = sm_walk_window<NS>(sh, pos, n, kd, t, G, GT, d, slice_off, chain, fields_g, Ap, Bp, Cp SM_PROF_PASS);
+            const int k = sm_walk_window<NS>(sh, pos, n, kd, t, G, GT, d, slice_off, chain, fields_g, Ap, Bp, Cp, win > 1 SM_PROF_PASS);
             total_acc += k;
             const bool final = pos >= n;
             SMX(unsigned long long th0; SMT(th0))
@@ -459,9 +471,7 @@ __global__ __launch_bounds__(256) void slice_sm_kernel(UpdateDesc d, SliceSync* 
                 }
                 if (broken && lane == 0) { __hip_atomic_store(&sy->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (info) atomicOr(info, 4); }
             }
-            __syncthreads();
-            for (int tt = t; tt < n; tt += 256) sh.diag0[tt] = ld_coh(G + tt + (long)n * tt);       // G changed: diagonal and prefetch restart from memory
-            __syncthreads();
+            __syncthreads();                                          // G changed: the next window reloads the diagonal and restarts its prefetch
             SMX({ unsigned long long th1; SMT(th1) t_hand += th1 - th0; })
         }
         if (t == 0) d.acc_out[(long)chain * d.acc_stride + acc_slot] = total_acc;
