@@ -1,5 +1,5 @@
 """Time the single-matrix GEMM in situ (wraps back to back on an engine's stream) and check it against numpy.
-usage: python scripts/gemm_time.py [L ...]   (lattice lengths; default 16 18 20 24 32)"""
+usage: python scripts/gemm_time.py [L | L1xL2 ...]   (lattice lengths; default 16 18 20 24 32)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -7,13 +7,14 @@ import dqmc_amd
 
 lib = dqmc_amd.lib()
 rng = np.random.default_rng(1)
-for L in [int(x) for x in (sys.argv[1:] or ["16", "18", "20", "24", "32"])]:
-    n = L * L
+for spec in (sys.argv[1:] or ["16", "18", "20", "24", "32"]):
+    L1, L2 = (int(x) for x in spec.split("x")) if "x" in spec else (int(spec), int(spec))
+    n = L1 * L2
     A = rng.standard_normal((n, n)); B = rng.standard_normal((n, n))
     for ta in (False, True):
         got = lib.gemm(A, B, transA=ta); want = (A.T if ta else A) @ B
         assert np.abs(got - want).max() < 1e-10 * np.abs(want).max(), (n, ta)
-    m = dqmc_amd.HubbardModel(L, L, 4.0, 2.0, 20)
+    m = dqmc_amd.HubbardModel(L1, L2, 4.0, 2.0, 20)
     e = m.engine(lib); e.set_fields(m.random_fields(1)); e.set_G(np.eye(n))
     for _ in range(5):
         e.wrap_forward(0); e.wrap_backward(0)
