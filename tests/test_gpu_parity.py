@@ -309,6 +309,34 @@ def test_batched_engine(hip, orc):
         assert st[c].n_accepted == os_[c].stats().n_accepted
 
 
+@pytest.mark.parametrize("L1,L2,C", [(10, 10, 3), (20, 20, 2), (17, 17, 2)])
+def test_batched_engine_at_ragged_and_large_sizes(hip, orc, L1, L2, C):
+    """Few chains per engine at N = 100 (not a multiple of 16: partial blocks in the blocked triangular solve and the Gauss-Jordan
+    panels), N = 400 and N = 289 (batched LDS-staged GEMM with a ragged last stage, 10-wave Gauss-Jordan panels, cooperative QRCP
+    for two matrices at once): G after initialisation and after a half sweep, fields and accepted counts, per chain against the oracle."""
+    m = HubbardModel(L1=L1, L2=L2, U=4.0, beta=1.0, nt=10, n_stab=5)
+    f = np.stack([m.random_fields(40 + c) for c in range(C)])
+    fast = orc.set_backend("lapack")
+    try:
+        e = m.engine(hip, n_chains=C); e.set_fields(f); e.init()
+        os_ = []
+        for c in range(C):
+            o = m.engine(orc); o.set_fields(f[c]); o.init(); os_.append(o)
+        G = e.get_G()
+        for c in range(C):
+            assert close(G[c], os_[c].get_G()), c
+        rng = np.random.default_rng(8)
+        streams = [m.random_stream(rng) for _ in range(C)]
+        e.sweep_0_to_beta(*(np.stack([st[k] for st in streams]) for k in range(3)))
+        G = e.get_G(); fe = e.get_fields(); st = e.stats()
+        for c in range(C):
+            os_[c].sweep_0_to_beta(*streams[c])
+            assert (fe[c] == os_[c].get_fields()).all() and close(G[c], os_[c].get_G()), c
+            assert st[c].n_accepted == os_[c].stats().n_accepted
+    finally:
+        orc.set_backend("builtin")
+
+
 def test_large_batch_uses_throughput_gemm(hip, orc):
     """256 chains of cfg 2 in one engine: enough 64x64 tiles for the LDS-tiled throughput GEMM
     (gemm_tile64_kernel) to be selected; a sample of chains is checked against the oracle."""
