@@ -46,7 +46,7 @@ ABI_SYMBOLS = [
     "create", "create_batch", "n_chains", "destroy", "set_fields", "get_fields", "init", "get_G", "set_G", "get_logdet",
     "n_stack", "get_stack", "sweep_0_to_beta", "sweep_beta_to_0", "sync", "get_stats",
     "wrap_forward", "wrap_backward", "local_update_slice", "calculate_Bbar", "global_action", "set_checkerboard",
-    "update_kernel_time", "set_profiling",
+    "update_kernel_time", "set_profiling", "slice_path",
     "measure_equal_time", "measure_accumulate", "measure_fetch",
     "sweep_unequal_time", "get_G_tau", "measure_unequal_time", "measure_unequal_fetch",
     "comm_unique_id", "comm_create_rccl", "comm_create_callbacks", "comm_destroy", "comm_rank", "comm_world_size",
@@ -111,6 +111,8 @@ class DqmcLib:
         g("set_checkerboard").argtypes = [C.c_void_p, C.c_int, c_int32_p, c_int32_p, c_double_p, c_double_p, c_double_p]
         g("update_kernel_time").argtypes = [C.c_void_p, c_double_p, c_int64_p, c_int64_p]
         g("set_profiling").argtypes = [C.c_void_p, C.c_int]
+        if self.has_symbol("slice_path"):
+            g("slice_path").argtypes = [C.c_void_p]
         if self.has_symbol("measure_equal_time"):
             g("measure_equal_time").argtypes = [C.c_void_p, C.c_int, C.c_int, c_double_p, c_double_p]
             g("measure_accumulate").argtypes = [C.c_void_p, C.c_int, C.c_int]
@@ -467,6 +469,10 @@ class Engine:
         out = np.empty(self.C * 3 * (self.nt + 1) * L1 * L2); cnt = np.zeros(1, dtype=np.int64)
         self._c("measure_unequal_fetch", _p(out), cnt.ctypes.data_as(c_int64_p), 1 if reset else 0)
         return self._ut_cube(out, L1, L2), int(cnt[0])
+
+    def slice_path(self) -> int:
+        """dqmc_slice_path: 1 = persistent single-launch slice kernel, 0 = scan / flush kernel pairs."""
+        return int(self.lib._sym("slice_path")(self._h))
 
     def set_profiling(self, on: bool):
         self._c("set_profiling", int(bool(on)))

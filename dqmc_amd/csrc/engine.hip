@@ -1012,6 +1012,13 @@ int dqmc_update_kernel_time(dqmc_engine* h, double* ms, int64_t* n_launches, int
     e.upd_ms = 0.0; e.upd_launches = 0; e.upd_accept_base = acc;
     return 0;
 }
+// diagnostic: 1 when the next local update of this engine takes a persistent single-launch slice kernel (it holds a CU reservation,
+// no hand-off has timed out, and at most DQMC_SLICE_MAX_ENGINES engines of this process share the device), 0 for the kernel pairs
+int dqmc_slice_path(dqmc_engine* h) {
+    if (!h) return -1;
+    Engine& e = h->e;
+    return (e.persistent && !e.handoff_failed && slice_persistent_allowed(e.device)) ? 1 : 0;
+}
 int dqmc_set_profiling(dqmc_engine* h, int on) {
     CHECK_E(h); Engine& e = h->e; DQ_HIP(hipSetDevice(e.device)); DQ_TRY(e.sync_and_check());
     e.profiling = on != 0; return 0;

@@ -603,12 +603,17 @@ def test_batched_engine_matches_single_chain_engines(hip):
 def test_bitwise_reproducible_at_full_size(hip):
     """Same inputs, two engines: G, fields, log det and the stabilisation errors agree BITWISE after a full cfg-3 sweep (no atomics in
     any reduction, fixed flush / split-K summation orders, hand-offs that publish complete windows only)."""
+    import gc
     m = HubbardModel(**CONFIGS["cfg3"]); rng = np.random.default_rng(31)
     f0 = m.random_fields(9); sf, sb = m.random_stream(rng), m.random_stream(rng)
     res = []
+    gc.collect()                                   # engines of earlier tests still waiting for the collector count towards DQMC_SLICE_MAX_ENGINES
     for _ in range(2):
-        e = m.engine(hip); e.set_fields(f0); e.init(); e.sweep_0_to_beta(*sf); e.sweep_beta_to_0(*sb)
-        st = e.stats(); res.append((e.get_G(), e.get_fields(), e.get_logdet(), st.max_err, st.n_accepted))
+        with m.engine(hip) as e:                   # one engine alive at a time: both runs take the same slice path
+            path0 = e.slice_path()
+            e.set_fields(f0); e.init(); e.sweep_0_to_beta(*sf); e.sweep_beta_to_0(*sb)
+            st = e.stats(); res.append((e.get_G(), e.get_fields(), e.get_logdet(), st.max_err, st.n_accepted, path0, e.slice_path()))
+    assert res[0][5] == res[0][6] == res[1][5] == res[1][6], [r[5:] for r in res]     # the wrap error between stabilisations depends on the path (summation order)
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
     assert res[0][2] == res[1][2] and res[0][3] == res[1][3] and res[0][4] == res[1][4]
 
