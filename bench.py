@@ -395,7 +395,9 @@ def main():
             out["replica_exchange"] = rex
         print(json.dumps(out), flush=True)
     if rex is not None and rex.get("hung"):
-        sys.stdout.flush(); os._exit(0)              # a communicator that never formed cannot be torn down either; the JSON line carries the error
+        # a communicator that never formed cannot be torn down either: leave without teardown, but NOT with success -- the JSON line
+        # (already printed, "hung": true) carries the measurement, exit code 3 tells the driver that the post-timing RCCL check hung
+        sys.stdout.flush(); sys.stderr.flush(); os._exit(3)
     eng.close()
     finalize(d)
 

@@ -29,8 +29,14 @@ def ldr_mat(F):
 
 
 def close(a, b, tol=TOL):
+    """i.i.d. inputs: tol relative to the largest entry (the header's second bound)."""
     a = np.asarray(a); b = np.asarray(b)
     return np.abs(a - b).max() <= tol * max(1.0, np.abs(b).max())
+
+
+def close_abs(a, b, tol=TOL):
+    """thermalised inputs: the north-star bound itself, max|dG| <= 1e-10 ABSOLUTE."""
+    return np.abs(np.asarray(a) - np.asarray(b)).max() <= tol
 
 
 def graded(rng, n, lo=-6, hi=6):
@@ -532,17 +538,21 @@ def test_unequal_time_parity(hip, orc, cfg, tol):
             o2 = m.engine(orc); o2.set_fields(f0); o2.init(); o2.sweep_0_to_beta(*sf); o2.sweep_beta_to_0(*sb); o2.sweep_unequal_time()
         finally:
             orc.set_backend("builtin")
-    worst = 0.0; floor = 0.0
+    worst = 0.0; floor = 0.0; worst_abs = 0.0; gmax = 0.0
     for which in ("tt", "t0", "0t"):
         for l in (range(m.nt + 1) if m.nt <= 80 else list(range(0, m.nt + 1, 7)) + [m.nt - 1, m.nt]):
             a, b = e.get_G_tau(which, l), o.get_G_tau(which, l)
             worst = max(worst, np.abs(a - b).max() / max(1.0, np.abs(b).max()))
+            worst_abs = max(worst_abs, np.abs(a - b).max()); gmax = max(gmax, np.abs(b).max())
             if o2 is not None:
                 floor = max(floor, np.abs(o2.get_G_tau(which, l) - b).max() / max(1.0, np.abs(b).max()))
     tol = max(tol, 5.0 * floor)
     print(f"{cfg}{' (thermalised)' if therm else ''}: CPU-vs-CPU floor {floor:.2e}")
-    print(f"{cfg}: unequal-time max rel err {worst:.2e}")
-    assert worst < tol
+    print(f"{cfg}: unequal-time max rel err {worst:.2e}, max abs err {worst_abs:.2e} (largest entry {gmax:.2e})")
+    if therm:
+        assert worst_abs <= TOL                      # thermalised input: 1e-10 absolute, every slice of Gtt, Gt0, G0t
+    else:
+        assert worst < tol
     se, so = e.stats(), o.stats()
     # the wrap errors themselves are rounding noise of the propagation (1e-9 .. 1e-5): same count, same order of magnitude
     assert se.n_err == so.n_err and se.max_err < 1e-6 + 100 * so.max_err and so.max_err < 1e-6 + 100 * se.max_err
@@ -654,15 +664,18 @@ def test_golden_vectors(hip, name):
     z, m, streams = golden_util.load(name)
     e = m.engine(hip); e.set_fields(z["fields"]); e.init()
     err, scale = golden_util.g0_error(z, e.get_G())
-    print(f"{name}: max|dG| = {err:.3e} (max|G| = {scale:.3e}, tol {float(z['tol']):.0e})")
-    assert err <= float(z["tol"]) * scale
+    therm = "therm_sweeps" in z.files and int(z["therm_sweeps"]) > 0        # thermalised fixture: 1e-10 ABSOLUTE; i.i.d. fixture: relative to max|G|
+    bound = float(z["tol"]) * (1.0 if therm else scale)
+    print(f"{name}: max|dG| = {err:.3e} (max|G| = {scale:.3e}, bound {bound:.1e} {'absolute' if therm else 'relative'})")
+    assert err <= bound
     assert abs(e.get_logdet() - float(z["logdet"])) < 1e-8 * max(1.0, abs(float(z["logdet"])))
     if streams is not None:
         e.sweep_0_to_beta(*streams[0]); e.sweep_beta_to_0(*streams[1])
         assert (e.get_fields() == z["fields_after"]).all()
         errA = np.abs(e.get_G() - z["G_after"]).max(); scaleA = max(1.0, np.abs(z["G_after"]).max())
-        print(f"{name}: after sweep max|dG| = {errA:.3e} (max|G| = {scaleA:.3e})")
-        assert errA <= float(z["tol"]) * scaleA
+        # CPU-vs-CPU floor of this very quantity (numpy/scipy against the C++ oracle with MKL): 3.7e-12 ... 1.1e-11
+        print(f"{name}: after sweep max|dG| = {errA:.3e} absolute (max|G| = {scaleA:.3e}; CPU-vs-CPU floor 3.7e-12 ... 1.1e-11)")
+        assert errA <= float(z["tol"]) * (1.0 if therm else scaleA)
         assert e.stats().n_accepted == int(z["n_accepted"])
 
 
