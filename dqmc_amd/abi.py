@@ -48,7 +48,7 @@ ABI_SYMBOLS = [
     "wrap_forward", "wrap_backward", "local_update_slice", "calculate_Bbar", "global_action", "set_checkerboard",
     "update_kernel_time", "set_profiling", "slice_path",
     "measure_equal_time", "measure_accumulate", "measure_fetch",
-    "sweep_unequal_time", "get_G_tau", "measure_unequal_time", "measure_unequal_fetch",
+    "sweep_unequal_time", "get_G_tau", "half_warp", "measure_unequal_time", "measure_unequal_fetch",
     "comm_unique_id", "comm_create_rccl", "comm_create_callbacks", "comm_destroy", "comm_rank", "comm_world_size",
     "comm_transport", "comm_barrier", "comm_allreduce_sum", "comm_selftest", "partner_rank", "replica_exchange_round",
 ]
@@ -120,6 +120,8 @@ class DqmcLib:
         if self.has_symbol("sweep_unequal_time"):
             g("sweep_unequal_time").argtypes = [C.c_void_p]
             g("get_G_tau").argtypes = [C.c_void_p, C.c_int, C.c_int, c_double_p]
+        if self.has_symbol("half_warp"):
+            g("half_warp").argtypes = [C.c_void_p, c_double_p, c_double_p, C.c_int, C.c_int, c_double_p]
             g("measure_unequal_time").argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, c_double_p]
             g("measure_unequal_fetch").argtypes = [C.c_void_p, c_double_p, c_int64_p, C.c_int]
         if self.has_symbol("replica_exchange_round"):
@@ -453,6 +455,14 @@ class Engine:
     def get_G_tau(self, which: str, l: int) -> np.ndarray:
         """which in {"tt", "t0", "0t"}: Gtt[l], Gt0[l] = G(tau_l, 0), G0t[l] = G(0, tau_l) of the last sweep_unequal_time."""
         B = np.empty(self.C * self.n * self.n); self._c("get_G_tau", {"tt": 0, "t0": 1, "0t": 2}[which], int(l), _p(B)); return self._mats_out(B)
+
+    def half_warp(self, expK_half=None, invexpK_half=None, which: str = "G", l: int = 0) -> np.ndarray:
+        """DQMC::half_warp (source/dqmc.cpp:288-315): invexpK_half @ M @ expK_half, M = the current G ("G") or Gtt / Gt0 / G0t[l]
+        ("tt" / "t0" / "0t"); the matrices may be omitted after the first call."""
+        a = _f64(expK_half) if expK_half is not None else None; b = _f64(invexpK_half) if invexpK_half is not None else None
+        B = np.empty(self.C * self.n * self.n)
+        self._c("half_warp", _p(a) if a is not None else None, _p(b) if b is not None else None, {"G": -1, "tt": 0, "t0": 1, "0t": 2}[which], int(l), _p(B))
+        return self._mats_out(B)
 
     def _ut_cube(self, flat, L1, L2):
         a = flat.reshape(self.C, 3, self.nt + 1, L2, L1).transpose(0, 1, 2, 4, 3)      # [chain][obs][tau][dx_idx][dy_idx]

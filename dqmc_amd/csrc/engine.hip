@@ -221,6 +221,8 @@ struct Engine {
     hipStream_t s = nullptr;
 
     double* expK = nullptr; double* invexpK = nullptr;           // [C][nn]
+    double* expKh = nullptr; double* invexpKh = nullptr;         // [nn] each: exp(-+ dtau K / 2) of dqmc_half_warp, uploaded on first use
+    double* hwOut = nullptr;                                     // [C][nn] result of dqmc_half_warp
     // checkerboard break-up of exp(-+dtau K) (dqmc_set_checkerboard): wraps and B-bar products apply the pair factors directly
     bool cb = false; int cb_groups = 0;
     int* cb_partner = nullptr;                                   // [cb_groups][n]
@@ -282,7 +284,7 @@ struct Engine {
         if (counted) slice_engine_destroyed(device);
         for (auto& p : ev_pairs) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
         if (stage_free) (void)hipEventDestroy(stage_free);
-        void* ptrs[] = {utMeasNow, utMeasSum, utG[0], utG[1], utG[2], utTmp, utErr, utL[0], utL[1], utD[0], utD[1], utR[0], utR[1], utP[0], utP[1], meas_now, meas_sum, GT, slice_sync, prep, stackP, expK, invexpK, cb_partner, cb_par, fields, expv, invexpv, tabs, tab8, G, Gtmp, bb0, bb1, stackL, stackD, stackR, tmpL, tmpD, tmpR,
+        void* ptrs[] = {expKh, invexpKh, hwOut, utMeasNow, utMeasSum, utG[0], utG[1], utG[2], utTmp, utErr, utL[0], utL[1], utD[0], utD[1], utR[0], utR[1], utP[0], utP[1], meas_now, meas_sum, GT, slice_sync, prep, stackP, expK, invexpK, cb_partner, cb_par, fields, expv, invexpv, tabs, tab8, G, Gtmp, bb0, bb1, stackL, stackD, stackR, tmpL, tmpD, tmpR,
                         logdet, rs_perm, rs_k, rs_u, Upanel, Wpanel, Cpanel, ibuf, ijp, state, acc, err, dstats, r1scratch};
         for (void* p : ptrs) if (p) (void)hipFree(p);
         if (h_stage) (void)hipHostFree(h_stage);
@@ -945,6 +947,26 @@ int dqmc_get_G_tau(dqmc_engine* h, int which, int l, double* out) {
     if (!e.ut_valid) { set_error("get_G_tau: run dqmc_sweep_unequal_time first"); return DQMC_EINVAL; }
     DQ_TRY(e.sync_and_check());
     DQ_HIP(hipMemcpy(out, e.utG[which] + (long)l * e.C * e.nn, sizeof(double) * e.C * e.nn, hipMemcpyDeviceToHost));
+    return 0;
+}
+// DQMC::half_warp (source/dqmc.cpp:288-315): invexpK_half * M * expK_half, two GEMMs on the engine's stream
+int dqmc_half_warp(dqmc_engine* h, const double* expK_half, const double* invexpK_half, int which, int l, double* out) {
+    CHECK_E(h); Engine& e = h->e; DQ_HIP(hipSetDevice(e.device));
+    if (!out) { set_error("half_warp: out is NULL"); return DQMC_EINVAL; }
+    if (which < -1 || which > 2 || (which >= 0 && (l < 0 || l > e.nt))) { set_error("half_warp: which in -1..2, l in 0..nt"); return DQMC_ERANGE; }
+    if (which >= 0 && !e.ut_valid) { set_error("half_warp: run dqmc_sweep_unequal_time first"); return DQMC_EINVAL; }
+    if ((expK_half == nullptr) != (invexpK_half == nullptr)) { set_error("half_warp: pass both half-step matrices or neither"); return DQMC_EINVAL; }
+    if (expK_half) {
+        if (!e.expKh) { DQ_TRY(e.dalloc(&e.expKh, e.nn)); DQ_TRY(e.dalloc(&e.invexpKh, e.nn)); DQ_TRY(e.dalloc(&e.hwOut, (size_t)e.C * e.nn)); }
+        DQ_HIP(hipStreamSynchronize(e.s));                         // pageable host memory: the copies below are synchronous with respect to the host
+        DQ_HIP(hipMemcpy(e.expKh, expK_half, sizeof(double) * e.nn, hipMemcpyHostToDevice));
+        DQ_HIP(hipMemcpy(e.invexpKh, invexpK_half, sizeof(double) * e.nn, hipMemcpyHostToDevice));
+    } else if (!e.expKh) { set_error("half_warp: no half-step matrices uploaded yet"); return DQMC_EINVAL; }
+    const CMat M = which < 0 ? CMat(e.G, e.nn) : CMat(e.utG[which] + (long)l * e.C * e.nn, e.nn);
+    DQ_TRY(e.ctx.gemm(CMat(e.invexpKh, 0), M, e.ctx.T(0)));                     // chain stride 0: one matrix for every chain
+    DQ_TRY(e.ctx.gemm(e.ctx.T(0), CMat(e.expKh, 0), Mat{e.hwOut, e.nn}));
+    DQ_TRY(e.sync_and_check());
+    DQ_HIP(hipMemcpy(out, e.hwOut, sizeof(double) * e.C * e.nn, hipMemcpyDeviceToHost));
     return 0;
 }
 int dqmc_measure_unequal_time(dqmc_engine* h, int L1, int L2, int accumulate, double* out) {

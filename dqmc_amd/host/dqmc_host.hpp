@@ -460,6 +460,21 @@ public:
         dqmc_detail::check(dqmc_get_G_tau(e_, (int)which, l, m.data())); return m;
     }
     bool isUnequalTime() const { return isUnequalTime_; }
+    // source/dqmc.cpp:288-315 (called at source/main.cpp:161-163 when [simulation] symmetric = true): GF_tosymm.Gtt[0] = invexpK_half *
+    // Gtt[0] * expK_half.  GF_asymm is the engine's device-resident G, so the second argument only keeps the reference's signature.  The
+    // reference also half-warps every slice of the unequal-time series (:306-313); here those stay in HBM and half_warp_tau() returns one
+    // half-warped slice on demand, like download_tau().
+    void half_warp(std::vector<GF>& GF_tosymm, std::vector<GF>& /*GF_asymm*/) {
+        const size_t nn = (size_t)model_.ns() * model_.ns();
+        for (int flv = 0; flv < model_.n_flavor(); ++flv) {
+            GF_tosymm.at(flv).Gtt0.resize(nn);
+            dqmc_detail::check(dqmc_half_warp(e_, model_.expK_half(flv).data(), model_.invexpK_half(flv).data(), -1, 0, GF_tosymm[flv].Gtt0.data()));
+        }
+    }
+    std::vector<double> half_warp_tau(Tau which, int l) {
+        std::vector<double> m((size_t)model_.ns() * model_.ns());
+        dqmc_detail::check(dqmc_half_warp(e_, model_.expK_half(0).data(), model_.invexpK_half(0).data(), (int)which, l, m.data())); return m;
+    }
     // greenTau / doublonTau / currxxTau (source/model.cpp:290-394) of the last sweep_unequalTime in displacement space:
     // [3][nt + 1][L1*L2]; measure_unequal() adds them to the device-side bin, fetch_unequal_bin() returns the bin averages
     std::vector<double> measure_unequal_time(const Lattice& lat) {

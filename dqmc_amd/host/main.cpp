@@ -100,6 +100,8 @@ int run_rank(const RunConfig& rc, int rank, int world_size, int device, dqmc_com
 
     std::vector<LDRStack> propagation_stacks(n_flavor);
     std::vector<GF> greens(n_flavor);
+    const bool symmetric = params.getBool("simulation", "symmetric", false);                   // source/main.cpp:75
+    std::vector<GF> greens_symm(symmetric ? n_flavor : 0);                                     // source/main.cpp:108-113
     for (int flv = 0; flv < n_flavor; flv++) {
         propagation_stacks[flv] = sim.init_stacks(flv);
         greens[flv] = sim.init_greenfunctions(propagation_stacks[flv]);
@@ -134,6 +136,7 @@ int run_rank(const RunConfig& rc, int rank, int world_size, int device, dqmc_com
         sim.sweep_0_to_beta(greens, propagation_stacks);
         sim.sweep_beta_to_0(greens, propagation_stacks);
         sim.sweep_unequalTime(greens, propagation_stacks);
+        if (symmetric) sim.half_warp(greens_symm, greens);          // source/main.cpp:161-163 (the reference measures `greens` all the same, :165)
         sim.measure(lat);                                          // measurements.measure(greens, lat), source/main.cpp:165 -- on the device, asynchronous
         sim.measure_unequal(lat);                                  // the dynamical observables of the same call, when isMeasureUnequalTime
         if (isweep % n_sweeps == 0) {                              // measurements.accumulate(lat), :167-169: one bin done

@@ -238,6 +238,17 @@ int dqmc_sweep_unequal_time(dqmc_engine* e);
  * l in 0..nt, out [n_chains][n*n] column-major.                                      */
 int dqmc_get_G_tau(dqmc_engine* e, int which, int l, double* out);
 
+/* DQMC::half_warp (source/dqmc.cpp:288-315, include/dqmc.h:87; called at source/main.cpp:161-163
+ * when [simulation] symmetric = true): out = invexpK_half * M * expK_half with
+ * expK_half = exp(-dtau K / 2) (AttractiveHubbard::expK_half / invexpK_half, include/model.h:41-42).
+ *   which = -1: M = the current equal-time G (GF::Gtt[0]); l ignored.
+ *   which = 0 / 1 / 2: M = Gtt[l] / Gt0[l] / G0t[l] of the last dqmc_sweep_unequal_time, l in 0..nt.
+ * expK_half / invexpK_half: [n*n] column-major, shared by all chains; both NULL = the pair of the
+ * previous call on this engine (the reference half-warps 3*nt matrices with one pair).
+ * out [n_chains][n*n] column-major.  The engine's own G / series are not modified (the reference
+ * writes into a second GF vector, GF_tosymm).                                                       */
+int dqmc_half_warp(dqmc_engine* e, const double* expK_half, const double* invexpK_half, int which, int l, double* out);
+
 /* Dynamical observables of the last dqmc_sweep_unequal_time in displacement space:
  * Observables::calculate_greenTau / calculate_doublonTau / calculate_currxxTau
  * (source/model.cpp:290-394) reduced per time slice as transform::chi_site_to_chi_r

@@ -746,6 +746,24 @@ int orc_get_G_tau(orc_engine* e, int which, int l, double* out) {
     if (e->ut[which].empty() || e->ut[which][l].empty()) return fail(EINVAL_, "get_G_tau: run sweep_unequal_time first");
     std::copy(e->ut[which][l].begin(), e->ut[which][l].end(), out); return OK;
 }
+/* DQMC::half_warp, source/dqmc.cpp:288-315: GF_tosymm.X[t] = invexpKhalf * GF_asymm.X[t] * expKhalf for X in {Gtt, Gt0, G0t}
+ * (:303-311); which = -1 is Gtt[0] as main.cpp sees it, i.e. the current equal-time G (:303).  The pair of matrices is kept
+ * for later calls with NULL arguments, as the product does.                                                                */
+int orc_half_warp(orc_engine* e, const double* expK_half, const double* invexpK_half, int which, int l, double* out) {
+    static thread_local vecd eh, ieh;
+    const int n = e->n; const size_t nn = (size_t)n * n;
+    if (!out) return fail(EINVAL_, "half_warp: out is NULL");
+    if (which < -1 || which > 2 || (which >= 0 && (l < 0 || l > e->nt))) return fail(ERANGE_, "half_warp: which in -1..2, l in 0..nt");
+    if (which >= 0 && (e->ut[which].empty() || e->ut[which][l].empty())) return fail(EINVAL_, "half_warp: run sweep_unequal_time first");
+    if ((expK_half == nullptr) != (invexpK_half == nullptr)) return fail(EINVAL_, "half_warp: pass both half-step matrices or neither");
+    if (expK_half) { eh.assign(expK_half, expK_half + nn); ieh.assign(invexpK_half, invexpK_half + nn); }
+    else if (eh.size() != nn) return fail(EINVAL_, "half_warp: no half-step matrices uploaded yet");
+    const double* M = which < 0 ? e->G.data() : e->ut[which][l].data();
+    vecd T(nn);
+    gemm(n, ieh.data(), false, M, false, T.data());
+    gemm(n, T.data(), false, eh.data(), false, out);
+    return OK;
+}
 int orc_measure_unequal_time(orc_engine* e, int L1, int L2, int accumulate, double* out) {
     if (L1 < 1 || L2 < 1 || L1 * L2 != e->n) return fail(EINVAL_, "measure_unequal_time: L1*L2 must equal n_sites");
     if (e->ut[0].empty()) return fail(EINVAL_, "measure_unequal_time: run sweep_unequal_time first");

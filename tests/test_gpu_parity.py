@@ -568,6 +568,40 @@ def test_unequal_time_parity(hip, orc, cfg, tol):
         e2.get_G_tau("tt", 0)                  # before any sweep_unequal_time
 
 
+@pytest.mark.parametrize("cfg", ["cfg1", "cfg3"])
+def test_half_warp_parity(hip, orc, cfg):
+    """DQMC::half_warp (source/dqmc.cpp:288-315) on the device against the oracle's restatement and against numpy: the equal-time G and
+    slices of the three unequal-time series; the engine's own G stays as it was; error returns as the other series calls."""
+    from dqmc_amd.model import expm_sym
+    from dqmc_amd import DqmcError
+    m = HubbardModel(**CONFIGS[cfg]); rng = np.random.default_rng(9)
+    eh, ieh = expm_sym(-0.5 * m.dtau * m.K), expm_sym(0.5 * m.dtau * m.K)
+    f0 = golden_util.load("cfg3_therm")[0]["fields"] if cfg == "cfg3" else m.random_fields(31)
+    sf, sb = m.random_stream(rng), m.random_stream(rng)
+    e = m.engine(hip); o = m.engine(orc)
+    for x in (e, o):
+        x.set_fields(f0); x.init(); x.sweep_0_to_beta(*sf); x.sweep_beta_to_0(*sb)
+    with pytest.raises(DqmcError) as ei:
+        e.half_warp(eh, ieh, "tt", 0)                      # no series yet
+    assert ei.value.code == -1
+    G0 = e.get_G()
+    Hs, Ho = e.half_warp(eh, ieh), o.half_warp(eh, ieh)
+    scale = max(1.0, np.abs(Ho).max())
+    assert np.abs(Hs - Ho).max() <= TOL * (1.0 if cfg == "cfg3" else scale)          # thermalised input: absolute
+    assert np.abs(Hs - ieh @ G0 @ eh).max() <= 1e-12 * scale
+    for x in (e, o):
+        x.sweep_unequal_time()
+    for which in ("tt", "t0", "0t"):
+        for l in (0, m.n_stab, m.nt):
+            a, b = e.half_warp(None, None, which, l), o.half_warp(None, None, which, l)
+            assert np.abs(a - b).max() <= TOL * max(1.0, np.abs(b).max()), (which, l)
+            assert np.abs(a - ieh @ e.get_G_tau(which, l) @ eh).max() <= 1e-12 * max(1.0, np.abs(b).max())
+    assert np.abs(e.get_G() - G0).max() == 0
+    with pytest.raises(DqmcError) as ei:
+        e.half_warp(None, None, "tt", m.nt + 1)
+    assert ei.value.code == -4
+
+
 @pytest.mark.parametrize("shape", [(4, 4, 4.0, 2.0, 20), (6, 4, 4.0, 3.0, 30), (16, 16, 8.0, 8.0, 200)])
 def test_dynamical_observables_parity(hip, orc, shape):
     """greenTau / doublonTau / currxxTau cubes of the device against the oracle after sweep + sweep_unequal_time on both sides."""

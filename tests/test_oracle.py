@@ -241,3 +241,27 @@ def test_dynamical_observables_vs_numpy(orc):
     e.measure_unequal_time(L1, L2, accumulate=True); e.measure_unequal_time(L1, L2, accumulate=True)
     tot, cnt = e.measure_unequal_fetch(L1, L2)
     assert cnt == 2 and np.abs(tot - 2 * cube).max() < 1e-12 and e.measure_unequal_fetch(L1, L2)[1] == 0
+
+
+def test_half_warp_oracle(orc):
+    """DQMC::half_warp (source/dqmc.cpp:288-315): invexpK_half @ M @ expK_half for the equal-time G and for slices of the unequal-time
+    series, against plain numpy; exp(-dtau K / 2) squared is exp(-dtau K), so a half warp applied twice is a whole one."""
+    from dqmc_amd.model import expm_sym
+    m = HubbardModel(**CONFIGS["cfg1"]); rng = np.random.default_rng(8)
+    eh, ieh = expm_sym(-0.5 * m.dtau * m.K), expm_sym(0.5 * m.dtau * m.K)
+    assert np.abs(eh @ eh - m.expK).max() < 1e-14
+    e = m.engine(orc); e.set_fields(m.random_fields(3)); e.init()
+    e.sweep_0_to_beta(*m.random_stream(rng)); e.sweep_beta_to_0(*m.random_stream(rng))
+    from dqmc_amd import DqmcError
+    with pytest.raises(DqmcError):
+        e.half_warp(eh, ieh, "tt", 0)                      # before sweep_unequal_time
+    G0 = e.get_G()
+    assert np.abs(e.half_warp(eh, ieh) - ieh @ G0 @ eh).max() < 1e-13
+    e.sweep_unequal_time()
+    for which in ("tt", "t0", "0t"):
+        for l in (0, 7, m.nt):
+            assert np.abs(e.half_warp(None, None, which, l) - ieh @ e.get_G_tau(which, l) @ eh).max() < 1e-13      # matrices kept from the first call
+    assert np.abs(e.get_G() - G0).max() == 0               # the engine's own G is untouched
+    with pytest.raises(DqmcError):
+        e.half_warp(eh, None)
+
