@@ -481,7 +481,8 @@ class Engine:
         return self._ut_cube(out, L1, L2), int(cnt[0])
 
     def slice_path(self) -> int:
-        """dqmc_slice_path: 1 = persistent single-launch slice kernel, 0 = scan / flush kernel pairs."""
+        """dqmc_slice_path: 0 = scan / flush kernel pairs, 1 = persistent single-launch slice kernel, 2 = persistent, and at least one
+        launch fell back (solo walk / untouched slice) because a flush workgroup was not resident in time."""
         return int(self.lib._sym("slice_path")(self._h))
 
     def set_profiling(self, on: bool):

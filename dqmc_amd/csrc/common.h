@@ -164,12 +164,32 @@ struct UpdateDesc {
     double* prep; long prep_stride;           // per chain 4*n doubles: the slice's G-independent proposal data
     Mat GT{nullptr, 0};                       // transposed copy of G the n <= 256 walk reads rows from; kept in step by the flushes
     int gt_valid = 0;                         // GT already equals G^T (written by the GEMM that produced G): skip the transpose launch
-    void* slice_sync = nullptr;               // per chain 64 zeroed bytes: hand-off words of the persistent slice kernel (null -> multi-kernel path)
+    void* slice_sync = nullptr;               // per chain SLICE_SYNC_BYTES: hand-off words of the persistent slice kernels (null -> multi-kernel path)
+    unsigned slice_epoch = 0;                 // launch number of the persistent slice kernel on this engine (1, 2, ...): every hand-off word carries it
+    int slice_absent_tile = -1;               // debug (DQMC_DEBUG_SLICE_ABSENT): this flush workgroup leaves at once, as if it had never become resident
     int* info = nullptr;                      // |= 4 when a hand-off of the persistent slice kernel timed out
     int* acc_out; long acc_stride;            // per chain per slice accepted counts [chain][2*nt] (+ offset chosen by caller)
     int n, nt;
 };
 constexpr int UPDATE_KD = 32;    // delayed-update window (accepted flips per flush)
+
+// ---- hand-off words of the persistent slice kernels (update.hip: slice_kernel, update_sm.hip: slice_sm_kernel) ----------------
+// One block per chain.  Every word a workgroup polls carries the LAUNCH number next to the window number:
+//   tag = (epoch << 8) | window,   epoch = 1, 2, ... per launch on the engine (UpdateDesc::slice_epoch), window = 0 .. 255
+// so a word left behind by an earlier launch can never match and nothing has to be re-armed when a launch ends (the round-2
+// kernels zeroed the words through an exit ticket: 66 stores and one atomic per workgroup on the tail of every launch).  The host
+// zeroes the block and restarts the epoch before it reaches 2^24 (Engine::next_slice_epoch).
+//   seq       walk -> flush: high word = tag of the window just closed, low word = k | solo << 30 | final << 31
+//   arrive[f] flush -> walk: tag of the last window flush workgroup f has absorbed; window 0 = "resident" (the census)
+struct SliceSync {
+    unsigned long long seq; unsigned int error; unsigned int solo_count; unsigned int pad[12];    // 64 B
+    unsigned int arrive[496];
+};
+constexpr size_t SLICE_SYNC_BYTES = 2048;
+static_assert(sizeof(SliceSync) == SLICE_SYNC_BYTES, "SliceSync layout");
+constexpr unsigned SLICE_EPOCH_LIMIT = 1u << 24;
+constexpr unsigned SLICE_SOLO_BIT = 1u << 30, SLICE_FINAL_BIT = 1u << 31;
+__host__ __device__ inline unsigned slice_tag(unsigned epoch, unsigned window) { return (epoch << 8) | window; }
 // one slice = reset + windows x (scan kernel, flush kernel)
 int launch_update_slice(const UpdateDesc& d, int l, int acc_slot, int n_chains, hipStream_t s);
 // sub-matrix variant of the persistent single-launch slice kernel (update_sm.hip)
@@ -178,9 +198,6 @@ int slice_flush_workgroups(int n);        // flush workgroups per chain of the p
 // CU reservation for the persistent single-launch slice kernel (see update.hip); an engine that holds one passes slice_sync
 bool slice_reserve(int device, int n, int n_chains);
 void slice_release(int device, int n, int n_chains);
-void slice_engine_created(int device);
-void slice_engine_destroyed(int device);
-bool slice_persistent_allowed(int device);    // false while more than three engines of this process share the device
 // standalone Sherman-Morrison rank-1 update (source/model.cpp:124-138), whole-chip streaming kernel
 int launch_rank1(Mat G, int i, double delta, double* scratch /*2n+1 doubles per chain*/, long scratch_stride, int n, int n_chains, hipStream_t s);
 

@@ -256,7 +256,8 @@ struct Engine {
     char* slice_sync = nullptr;                                  // [C][1 KiB] hand-off words of the persistent slice kernels
     bool persistent = false;                                     // holds a CU reservation for the single-launch slice kernel (slice_reserve)
     bool handoff_failed = false;                                 // a hand-off of a persistent kernel timed out once: this engine stays on the kernel pairs from then on
-    bool counted = false;                                        // registered in the per-device engine count (slice_engine_created)
+    unsigned slice_epoch = 0;                                    // launches of the persistent slice kernel so far: the tag of its hand-off words (SliceSync, common.h)
+    int slice_absent_tile = -1;                                  // DQMC_DEBUG_SLICE_ABSENT=<tile>, read when the engine is created: that flush workgroup never checks in (test of the solo fall-back)
     int* acc = nullptr;                                          // [C][nt]
     double* err = nullptr;                                       // [C][n_stack]
     DevStats* dstats = nullptr;                                  // [C]
@@ -281,7 +282,6 @@ struct Engine {
     ~Engine() {
         if (s) (void)hipStreamSynchronize(s);
         if (persistent) slice_release(device, n, C);
-        if (counted) slice_engine_destroyed(device);
         for (auto& p : ev_pairs) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
         if (stage_free) (void)hipEventDestroy(stage_free);
         void* ptrs[] = {expKh, invexpKh, hwOut, utMeasNow, utMeasSum, utG[0], utG[1], utG[2], utTmp, utErr, utL[0], utL[1], utD[0], utD[1], utR[0], utR[1], utP[0], utP[1], meas_now, meas_sum, GT, slice_sync, prep, stackP, expK, invexpK, cb_partner, cb_par, fields, expv, invexpv, tabs, tab8, G, Gtmp, bb0, bb1, stackL, stackD, stackR, tmpL, tmpD, tmpR,
@@ -301,7 +301,7 @@ struct Engine {
         g_host.assign(g, g + C); gamma_host.assign(gamma, gamma + 4); eta_host.assign(eta, eta + 4);
         DQ_TRY(ctx.init(n, C, device)); s = ctx.stream;
         persistent = slice_reserve(device, n, C);
-        slice_engine_created(device); counted = true;
+        if (const char* a = getenv("DQMC_DEBUG_SLICE_ABSENT")) slice_absent_tile = atoi(a);
         DQ_TRY(dalloc(&expK, C * nn)); DQ_TRY(dalloc(&invexpK, C * nn));
         DQ_TRY(dalloc(&fields, (size_t)C * nt * n)); DQ_TRY(dalloc(&expv, (size_t)C * nt * n)); DQ_TRY(dalloc(&invexpv, (size_t)C * nt * n));
         DQ_TRY(dalloc(&tabs, C)); DQ_TRY(dalloc(&tab8, (size_t)C * 8));
@@ -312,7 +312,7 @@ struct Engine {
         DQ_TRY(dalloc(&logdet, C));
         DQ_TRY(dalloc(&rs_perm, (size_t)C * nt * n)); DQ_TRY(dalloc(&rs_k, (size_t)C * nt * n)); DQ_TRY(dalloc(&rs_u, (size_t)C * nt * n));
         DQ_TRY(dalloc(&Upanel, (size_t)C * UPDATE_KD * n)); DQ_TRY(dalloc(&Wpanel, (size_t)C * UPDATE_KD * n)); DQ_TRY(dalloc(&Cpanel, (size_t)C * UPDATE_KD * UPDATE_KD));
-        DQ_TRY(dalloc(&state, (size_t)C * 4)); DQ_TRY(dalloc(&prep, (size_t)C * 4 * n)); DQ_TRY(dalloc(&meas_now, (size_t)C * (3 + n))); DQ_TRY(dalloc(&meas_sum, (size_t)C * (3 + n))); DQ_HIP(hipMemsetAsync(meas_sum, 0, sizeof(double) * C * (3 + n), s)); DQ_TRY(dalloc(&slice_sync, (size_t)C * 1024)); DQ_HIP(hipMemsetAsync(slice_sync, 0, (size_t)C * 1024, s)); DQ_TRY(dalloc(&acc, (size_t)C * nt)); DQ_TRY(dalloc(&err, (size_t)C * n_stack));
+        DQ_TRY(dalloc(&state, (size_t)C * 4)); DQ_TRY(dalloc(&prep, (size_t)C * 4 * n)); DQ_TRY(dalloc(&meas_now, (size_t)C * (3 + n))); DQ_TRY(dalloc(&meas_sum, (size_t)C * (3 + n))); DQ_HIP(hipMemsetAsync(meas_sum, 0, sizeof(double) * C * (3 + n), s)); DQ_TRY(dalloc(&slice_sync, (size_t)C * SLICE_SYNC_BYTES)); DQ_HIP(hipMemsetAsync(slice_sync, 0, (size_t)C * SLICE_SYNC_BYTES, s)); DQ_TRY(dalloc(&acc, (size_t)C * nt)); DQ_TRY(dalloc(&err, (size_t)C * n_stack));
         DQ_TRY(dalloc(&dstats, C)); DQ_TRY(dalloc(&r1scratch, (size_t)C * (2 * n + 1)));
         h_stage_bytes = (size_t)C * nt * n * (sizeof(int32_t) + sizeof(uint8_t) + sizeof(double));
         DQ_HIP(hipHostMalloc(&h_stage, h_stage_bytes, hipHostMallocDefault));
@@ -486,11 +486,11 @@ struct Engine {
         return ctx.gemm(ctx.T(0), CMat(expK, nn), mG(), CVec(), ev(l), CVec(), 0, 0, use_gt() ? Mat{GT, nn} : Mat{nullptr, 0});
     }
     // the walk reads rows of G from a transposed copy: the register walk (n <= 256) and the persistent sub-matrix kernel (any n)
-    bool use_gt() const { return n <= 256 || persistent; }       // (kept in step even while the persistent kernel is not being launched)
+    bool use_gt() const { return n <= 256 || (persistent && !handoff_failed); }     // n > 256: only the persistent sub-matrix kernel reads and maintains GT
     UpdateDesc udesc() const {
         UpdateDesc d; d.G = mG(); d.fields = fields; d.f_stride = (long)nt * n; d.expv = expv; d.invexpv = invexpv; d.v_stride = (long)nt * n;
         d.tabs = tabs; d.perm = rs_perm; d.kprop = rs_k; d.u = rs_u; d.rs_stride = (long)nt * n; d.Upanel = Upanel; d.Wpanel = Wpanel; d.Cpanel = Cpanel;
-        d.panel_stride = (long)UPDATE_KD * n; d.state = state; d.state_stride = 4; d.prep = prep; d.prep_stride = 4L * n; d.slice_sync = (persistent && !handoff_failed && slice_persistent_allowed(device)) ? slice_sync : nullptr; d.GT = Mat{GT, nn}; d.gt_valid = gt_valid ? 1 : 0; d.info = ctx.info(); d.acc_out = acc; d.acc_stride = nt; d.n = n; d.nt = nt;
+        d.panel_stride = (long)UPDATE_KD * n; d.state = state; d.state_stride = 4; d.prep = prep; d.prep_stride = 4L * n; d.slice_sync = (persistent && !handoff_failed) ? slice_sync : nullptr; d.slice_epoch = slice_epoch; d.slice_absent_tile = slice_absent_tile; d.GT = Mat{GT, nn}; d.gt_valid = gt_valid ? 1 : 0; d.info = ctx.info(); d.acc_out = acc; d.acc_stride = nt; d.n = n; d.nt = nt;
         return d;
     }
     int local_update(int l) {
@@ -499,6 +499,10 @@ struct Engine {
             if (ev_used == ev_pairs.size()) { hipEvent_t a, b; DQ_HIP(hipEventCreate(&a)); DQ_HIP(hipEventCreate(&b)); ev_pairs.emplace_back(a, b); }
             e0 = ev_pairs[ev_used].first; e1 = ev_pairs[ev_used].second; ++ev_used;
             DQ_HIP(hipEventRecord(e0, s));
+        }
+        if (persistent && !handoff_failed) {
+            // every launch of a persistent slice kernel gets its own number: the hand-off words carry it, so none has to be re-armed
+            if (++slice_epoch >= SLICE_EPOCH_LIMIT) { DQ_HIP(hipMemsetAsync(slice_sync, 0, (size_t)C * SLICE_SYNC_BYTES, s)); slice_epoch = 1; }
         }
         DQ_TRY(launch_update_slice(udesc(), l, l, C, s));
         if (profiling) DQ_HIP(hipEventRecord(e1, s));
@@ -632,7 +636,8 @@ struct Engine {
         }
         int h_info = 0;
         DQ_HIP(hipMemcpy(&h_info, ctx.info(), sizeof(int), hipMemcpyDeviceToHost));
-        if (h_info & 4) { handoff_failed = true; set_error("persistent slice kernel: a hand-off timed out (workgroups not co-resident?); the chain state is undefined -- set the fields again and call dqmc_init; this engine uses the scan / flush kernel pairs from now on"); (void)hipMemset(ctx.info(), 0, sizeof(int)); (void)hipMemset(slice_sync, 0, (size_t)C * 1024); return DQMC_ENUMERIC; }
+        if (h_info & 4) { handoff_failed = true; gt_valid = false; set_error("persistent slice kernel: a workgroup that had checked in stopped answering (device fault or pre-emption beyond the spin bound); the chain state is undefined -- set the fields again and call dqmc_init; this engine uses the scan / flush kernel pairs from now on"); (void)hipMemset(ctx.info(), 0, sizeof(int)); (void)hipMemset(slice_sync, 0, (size_t)C * SLICE_SYNC_BYTES); slice_epoch = 0; return DQMC_ENUMERIC; }
+        if (h_info & 8) { handoff_failed = true; gt_valid = false; set_error("persistent sub-matrix slice kernel: its workgroups did not all become resident (device shared with other work?); the slice was left untouched before anything was modified -- this engine uses the scan / flush kernel pairs from now on, re-run the sweep"); (void)hipMemset(ctx.info(), 0, sizeof(int)); return DQMC_ENUMERIC; }
         if (h_info & 2) { set_error("cooperative QRCP gave up waiting for a partner workgroup (not co-resident?)"); (void)hipMemset(ctx.info(), 0, sizeof(int)); return DQMC_ENUMERIC; }
         if (h_info) { set_error("LU factorisation hit a zero or NaN pivot"); (void)hipMemset(ctx.info(), 0, sizeof(int)); return DQMC_ENUMERIC; }
         return 0;
@@ -1034,12 +1039,19 @@ int dqmc_update_kernel_time(dqmc_engine* h, double* ms, int64_t* n_launches, int
     e.upd_ms = 0.0; e.upd_launches = 0; e.upd_accept_base = acc;
     return 0;
 }
-// diagnostic: 1 when the next local update of this engine takes a persistent single-launch slice kernel (it holds a CU reservation,
-// no hand-off has timed out, and at most DQMC_SLICE_MAX_ENGINES engines of this process share the device), 0 for the kernel pairs
+// diagnostic: 1 when the next local update of this engine takes a persistent single-launch slice kernel (it holds a CU reservation
+// and no hand-off has failed), 0 for the kernel pairs
 int dqmc_slice_path(dqmc_engine* h) {
     if (!h) return -1;
     Engine& e = h->e;
-    return (e.persistent && !e.handoff_failed && slice_persistent_allowed(e.device)) ? 1 : 0;
+    if (!(e.persistent && !e.handoff_failed)) return 0;
+    // 2: at least one launch of the persistent kernel fell back to the solo walk (a flush workgroup had not become resident in time)
+    unsigned solo = 0;
+    for (int c = 0; c < e.C && !solo; ++c) {
+        SliceSync hs; if (hipMemcpy(&hs, e.slice_sync + (size_t)c * SLICE_SYNC_BYTES, 64, hipMemcpyDeviceToHost) != hipSuccess) break;
+        solo = hs.solo_count;
+    }
+    return solo ? 2 : 1;
 }
 int dqmc_set_profiling(dqmc_engine* h, int on) {
     CHECK_E(h); Engine& e = h->e; DQ_HIP(hipSetDevice(e.device)); DQ_TRY(e.sync_and_check());

@@ -19,7 +19,6 @@
 //   scan_kernel<1024> + n > 256: the pending pairs live in LDS (scan_group), G rows are read directly (no GT).
 //   flush_kernel<false>
 #include "common.h"
-#include <atomic>
 #include <cstdlib>
 #include <mutex>
 #include "wave.h"
@@ -52,7 +51,7 @@ __device__ __forceinline__ void st_coh(double* p, double x) {
 // bytes of dynamic LDS: UW[kd][n] | diag, dlt, rbv, ur [n] | tables[32] | site[n] | newf[n] (padded) | (register variant) diag2[n]
 __host__ __device__ inline size_t scan_lds_bytes(int n, int kd, bool regs) {
     const size_t base = (((size_t)16 * kd * n + (size_t)n * 32 + 256 + (size_t)n * 4 + (size_t)n) + 63) & ~(size_t)63;
-    return base + (regs ? (size_t)n * 8 + 4 * UPDATE_KD : 0);
+    return base + (regs ? (size_t)n * 8 + 4 * (UPDATE_KD + 4) : 0);       // diag2 | acc_site[KD] | 4 spare words (verdicts of the persistent kernel's wave 0)
 }
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a workgroup-scope release fence, which on
@@ -546,152 +545,6 @@ __global__ __launch_bounds__(256) void flush_kernel(UpdateDesc d, int tiles_per_
                                a0, b0, n, k, kd, lane);
 }
 
-// ---- persistent slice kernel: the whole local update of one time slice in ONE launch --------------------------------
-// grid = (1 + F, chains): workgroup 0 of a chain runs the serial Metropolis walk (window after window); the other
-// F = (n/32)^2 workgroups each own one 32x32 tile of G (and its mirror in GT) and apply every window's low-rank
-// correction to it.  Replaces ceil(n/KD) x (scan launch + flush launch) per slice: per window the cost of two kernel
-// boundaries, a cold prologue and an empty-launch tail becomes one publish / arrive hand-off.
-//
-// Hand-off (cdna_hip_programming.md Guideline 16; placement-independent, every shared word an agent-scope access; ONE wave per
-// workgroup polls, arrivals are per-workgroup words read by the walk with one coalesced load -- no read-modify-write on the path):
-//   walk  -> flush : when a window closes the panel rows are written with sc1 stores, every wave drains
-//                    (s_waitcnt vmcnt(0)), the workgroup barriers, one lane stores the granule
-//                    {tag = window number, value = k | final << 31}.  Flush workgroups poll that ONE word.
-//   flush -> walk  : tiles are read and written with sc1 accesses; each flush wave drains, barrier, one lane stores the window
-//                    number into the workgroup's arrival word; the walk polls the F words (lane f <-> word f) until all carry the
-//                    window number, then restarts its prefetch with sc1 loads (no L1 copy of G is ever trusted; the diagonal
-//                    continues from the lane's running value).
-//   The words are zeroed by the LAST workgroup to leave (exit ticket), ready for the next launch; spins are bounded.
-// Needs all 1 + F workgroups of a chain co-resident (the walk's LDS allows one workgroup per CU), so the launcher only
-// takes this path while (1 + F) * chains fits the CU count, and falls back to the multi-kernel path otherwise.
-struct SliceSync { unsigned long long seq; unsigned int arrived; unsigned int exits; unsigned int error; unsigned int pad[11];   // 64 B
-                   unsigned int arrive[240]; };  // + one arrival word per flush workgroup (the first 64 are used here); 1 KiB per chain
-constexpr unsigned SLICE_SPIN_LIMIT = 1u << 20;
-
-__global__ __launch_bounds__(256) void slice_kernel(UpdateDesc d, SliceSync* sync_p, int l, int acc_slot, int kd, int tiles_per_dim, int* info) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int chain = blockIdx.y;
-    const int n = d.n;
-    const int F = tiles_per_dim * tiles_per_dim;
-    SliceSync* sy = sync_p + chain;
-    double* __restrict__ G = d.G.at(chain);
-    double* __restrict__ GT = d.GT.at(chain);
-    double* __restrict__ Up = d.Upanel + (long)chain * d.panel_stride;
-    double* __restrict__ Wp = d.Wpanel + (long)chain * d.panel_stride;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-
-    if (blockIdx.x > 0) {
-        // ================= flush role: one 32x32 tile of G, one 16x16 sub-tile per wave =================
-        const int tile = blockIdx.x - 1;
-        const int a0 = (tile % tiles_per_dim) * 32 + (wave & 1) * 16;
-        const int b0 = (tile / tiles_per_dim) * 32 + (wave >> 1) * 16;
-        // one wave polls the window word (64 workgroups x 4 waves polling one L2 line slow the walk's own loads: guide, Pitfall 9),
-        // the others wait at the barrier and take the word from LDS
-        unsigned long long* bcast = reinterpret_cast<unsigned long long*>(smem);
-        for (unsigned win = 1;; ++win) {
-            if (wave == 0) {
-                unsigned long long word = 0; unsigned spins = 0; bool give_up = false;
-                for (;;) {
-                    word = __hip_atomic_load(&sy->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if ((unsigned)(word >> 32) == win) break;
-                    if (++spins > SLICE_SPIN_LIMIT) { give_up = true; break; }
-                    __builtin_amdgcn_s_sleep(1);
-                }
-                if (give_up && lane == 0) { __hip_atomic_store(&sy->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (info) atomicOr(info, 4); }
-                if (lane == 0) bcast[win & 1] = give_up ? ~0ULL : word;
-            }
-            __syncthreads();
-            const unsigned long long word = bcast[win & 1];
-            if (word == ~0ULL) break;
-            const int k = (int)(word & 0x7fffffffULL);
-            const bool final = (word >> 31) & 1ULL;
-            if (k > 0 && a0 < n && b0 < n) flush_tile<true, true>(G, GT, Up, Wp, a0, b0, n, k, kd, lane);
-            if (final) break;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains before the arrival is signalled
-            __syncthreads();
-            // arrival: this workgroup's own word (no read-modify-write on a shared counter: 64 atomics on one word serialise in L2)
-            if (t == 0) __hip_atomic_store(&sy->arrive[tile], win, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    } else {
-        // ================= walk role =================
-        const int j = t;
-        const bool live = j < n;
-        ScanShared sh;
-        scan_shared_init(sh, smem, n, kd, true);
-        const double* tab_g = reinterpret_cast<const double*>(d.tabs + chain);
-        const long slice_off = (long)l * n;
-        int8_t* fields_g = d.fields + (long)chain * d.f_stride + slice_off;
-        double dg = 0.0;
-        if (live) {
-            const long off = (long)chain * d.rs_stride + slice_off + j;
-            const int i = d.perm[off];
-            const int kp = d.kprop[off];
-            const int old_f = fields_g[i];
-            sh.site[j] = i; sh.newf[j] = (signed char)c_proposal[old_f][kp];
-            sh.rbv[j] = tab_g[old_f * 3 + kp]; sh.dlt[j] = tab_g[12 + old_f * 3 + kp]; sh.ur[j] = d.u[off];
-            dg = G[j + (long)n * j];                                  // first window: G was written by the previous kernel
-            sh.diag[j] = dg;
-        }
-        if (j < 32) sh.tl[j] = tab_g[j];
-        __syncthreads();
-        int pos = 0, total_acc = 0;
-        bool broken = false;
-#ifdef DQ_SCAN_STAMPS
-        ScanProf prof; unsigned long long tk0, t_hand = 0; STAMP(tk0)
-#endif
-        for (unsigned win = 1;; ++win) {
-            const int k = walk_window<true>(sh, pos, dg, n, kd, j, live, G, GT, d, slice_off, chain, fields_g, Up, Wp PROF_PASS);
-            total_acc += k;
-            const bool final = pos >= n;
-#ifdef DQ_SCAN_STAMPS
-            unsigned long long th0; STAMP(th0)
-#endif
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // panel stores of every wave have left the CU
-            __syncthreads();
-            if (t == 0) __hip_atomic_store(&sy->seq, ((unsigned long long)win << 32) | ((unsigned long long)final << 31) | (unsigned long long)k,
-                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (final) break;
-            // wait until every tile has absorbed this window, then refresh the diagonal from the flushed G
-            if (wave == 0) {
-                unsigned spins = 0;
-                for (;;) {                                            // lane f <-> flush workgroup f (F <= 64): one coalesced load per poll
-                    const unsigned a = lane < F ? __hip_atomic_load(&sy->arrive[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : win;
-                    if (__all(a == win)) break;
-                    if (++spins > SLICE_SPIN_LIMIT) { broken = true; break; }
-                    __builtin_amdgcn_s_sleep(1);
-                }
-                if (broken && lane == 0) { __hip_atomic_store(&sy->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (info) atomicOr(info, 4); }
-            }
-            __syncthreads();
-            // G changed: the prefetch restarts from memory.  The diagonal does not: the lane's running value dg (advanced by pu * wj at
-            // every accepted flip) IS G_jj after the flush up to the summation order, so the next window starts from it instead of
-            // paying an L2 round trip in front of the prefetch (it is re-read from G at the start of every slice)
-            if (live) sh.diag[j] = dg;
-            __syncthreads();
-#ifdef DQ_SCAN_STAMPS
-            { unsigned long long th1; STAMP(th1) t_hand += th1 - th0; }
-#endif
-        }
-        if (j == 0) d.acc_out[(long)chain * d.acc_stride + acc_slot] = total_acc;
-#ifdef DQ_SCAN_STAMPS
-        if (j == 0) { unsigned long long tk1; STAMP(tk1)
-            printf("slice l=%d: total %llu cyc | hand-offs %llu | %d acc: decide+fetch %llu pairs %llu tail %llu | window start->first flip %llu | %d empty passes %llu | dump+drain %llu\n",
-                   l, tk1 - tk0, t_hand, prof.n_acc, prof.t_wait, prof.t_kloop, prof.t_tail, prof.t_first, prof.n_noacc, prof.t_noacc, prof.t_dump); }
-#endif
-    }
-    // exit ticket: the last workgroup of the chain to leave re-arms the sync words for the next launch
-    __syncthreads();
-    if (t == 0) {
-        const unsigned ticket = __hip_atomic_fetch_add(&sy->exits, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (ticket == (unsigned)F) {
-            __hip_atomic_store(&sy->seq, 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&sy->arrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            for (int f = 0; f < 64; ++f) __hip_atomic_store(&sy->arrive[f], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&sy->exits, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-}
-
 // ---- solo slice kernel: one workgroup per chain does the walk AND its own flushes --------------------------------------
 // For engines with many chains the single-launch kernel above cannot be used (its 1 + (n/32)^2 workgroups per chain must all
 // be resident), and the scan / flush kernel pairs cost 2 x ceil(N/KD) launches per slice with every chain waiting for the
@@ -743,6 +596,193 @@ __device__ __forceinline__ void flush_tiles_lds(double* __restrict__ G, double* 
             if (a_ok && bb < n) G[a + (long)n * bb] = gv[q][reg] + acc[reg];
             if (b_ok && aa < n) GT[b + (long)n * aa] = gt[q][reg] + acc_t[reg];
         }
+    }
+}
+
+// ---- persistent slice kernel: the whole local update of one time slice in ONE launch --------------------------------
+// grid = (1 + F, chains): workgroup 0 of a chain runs the serial Metropolis walk (window after window); the other
+// F = (n/32)^2 workgroups each own one 32x32 tile of G (and its mirror in GT) and apply every window's low-rank
+// correction to it.  Replaces ceil(n/KD) x (scan launch + flush launch) per slice: per window the cost of two kernel
+// boundaries, a cold prologue and an empty-launch tail becomes one publish / arrive hand-off.
+//
+// Hand-off (SliceSync in common.h; cdna_hip_programming.md Guideline 16, form R1).  Every shared byte -- panel rows, G / GT tiles,
+// the words -- is written and read with agent-scope relaxed atomics (global_store / global_load ... sc1: write-through, served
+// past the CU's L1), ONE wave per workgroup polls, arrivals are per-workgroup words read by the walk with one coalesced load:
+//   walk  -> flush : when a window closes the panel rows are stored, every storing wave drains (s_waitcnt vmcnt(0): an agent-scope
+//                    store that has retired is performed at agent scope -- the same property the architected store-release
+//                    sequence "buffer_wbl2 sc1; s_waitcnt vmcnt(0); store sc1" relies on for the stores in front of it), the
+//                    workgroup barriers, one lane stores seq = {tag, k | flags}.  Flush workgroups poll that ONE word; their
+//                    payload loads are issued after the poll has matched (branch on the loaded value) and a workgroup barrier.
+//   flush -> walk  : tiles are read and written the same way; each flush wave drains, barrier, one lane stores the tag into the
+//                    workgroup's arrival word; the walk polls the F words (lane f <-> word f) until all carry the tag, barriers,
+//                    then restarts its prefetch (the diagonal continues from the lane's running value).
+//   No plain load ever touches a byte another workgroup writes during the launch, so no acquire fence (buffer_inv sc1: drops the
+//   L1 copies a plain load could hit) is needed; no plain store carries payload, so no release fence (buffer_wbl2 sc1: writes back
+//   dirty L2 lines) is needed.  scripts/handoff_litmus.hip checks exactly these instruction forms word by word under load.
+// Tags carry the launch number (slice_tag), so no word is re-armed and no word of an earlier launch can match.
+// Residency is CHECKED, not assumed: every flush workgroup checks in (arrive[f] = tag of window 0) before it polls; before the
+// walk publishes its FIRST window -- before it has modified anything but its own registers and LDS -- it looks for all F
+// check-ins (they arrived long ago: the first window takes ~30 us) and, when some are still missing after a bounded wait,
+// publishes the SOLO flag instead: flush workgroups that are or become resident leave without touching G, and the walk
+// workgroup applies every window itself from its LDS pair store (flush_tiles_lds, the solo kernel's flush).  Once all have
+// checked in, every later hand-off completes in bounded time (resident workgroups always make progress), so the spin bounds
+// below are a net for device faults only.
+// the solo fall-back's flush as a real function call: inlined, its registers join the walk's allocation problem and the hot loop of
+// the walk ends up with tuple copies and scratch spills (seen in the ISA); a call happens between windows, where almost nothing is live
+__device__ __attribute__((noinline)) void solo_flush(double* G, double* GT, const double2* UW, int n, int k) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tiles16 = (n + 15) / 16, n_st = tiles16 * tiles16;
+    for (int st = wave; st < n_st; st += 4 * 4) flush_tiles_lds<4>(G, GT, UW, st, 4, n_st, tiles16, n, k, lane);
+}
+constexpr unsigned SLICE_SPIN_LIMIT = 1u << 22;     // polls (>= 1 us each) a resident partner is given
+constexpr unsigned SLICE_CENSUS_SPINS = 256;        // polls the walk grants late flush workgroups before it goes solo (~100-200 us)
+
+__global__ __launch_bounds__(256) void slice_kernel(UpdateDesc d, SliceSync* sync_p, int l, int acc_slot, int kd, int tiles_per_dim, int* info) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int chain = blockIdx.y;
+    const int n = d.n;
+    const int F = tiles_per_dim * tiles_per_dim;
+    SliceSync* sy = sync_p + chain;
+    double* __restrict__ G = d.G.at(chain);
+    double* __restrict__ GT = d.GT.at(chain);
+    double* __restrict__ Up = d.Upanel + (long)chain * d.panel_stride;
+    double* __restrict__ Wp = d.Wpanel + (long)chain * d.panel_stride;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const unsigned epoch = d.slice_epoch;
+
+    if (blockIdx.x > 0) {
+        // ================= flush role: one 32x32 tile of G, one 16x16 sub-tile per wave =================
+        const int tile = blockIdx.x - 1;
+        if (tile == d.slice_absent_tile) return;                      // debug: a workgroup that never becomes resident
+        const int a0 = (tile % tiles_per_dim) * 32 + (wave & 1) * 16;
+        const int b0 = (tile / tiles_per_dim) * 32 + (wave >> 1) * 16;
+        if (t == 0) __hip_atomic_store(&sy->arrive[tile], slice_tag(epoch, 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // census: resident
+        // one wave polls the window word (64 workgroups x 4 waves polling one L2 line slow the walk's own loads: guide, Pitfall 9),
+        // the others wait at the barrier and take the word from LDS
+        unsigned long long* bcast = reinterpret_cast<unsigned long long*>(smem);
+        for (unsigned win = 1;; ++win) {
+            if (wave == 0) {
+                unsigned long long word = 0; unsigned spins = 0; bool give_up = false;
+                for (;;) {
+                    word = __hip_atomic_load(&sy->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((unsigned)(word >> 32) == slice_tag(epoch, win)) break;
+                    if (++spins > SLICE_SPIN_LIMIT) { give_up = true; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (give_up && lane == 0) { __hip_atomic_store(&sy->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (info) atomicOr(info, 4); }
+                if (lane == 0) bcast[win & 1] = give_up ? ~0ULL : word;
+            }
+            __syncthreads();
+            const unsigned long long word = bcast[win & 1];
+            if (word == ~0ULL) break;
+            const unsigned lo = (unsigned)word;
+            if (lo & SLICE_SOLO_BIT) break;                           // the walk applies the windows itself: G is not ours to touch
+            const int k = (int)(lo & 0x3fffffffu);
+            const bool final = (lo & SLICE_FINAL_BIT) != 0;
+            if (k > 0 && a0 < n && b0 < n) flush_tile<true, true>(G, GT, Up, Wp, a0, b0, n, k, kd, lane);
+            if (final) break;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains before the arrival is signalled
+            __syncthreads();
+            // arrival: this workgroup's own word (no read-modify-write on a shared counter: 64 atomics on one word serialise in L2)
+            if (t == 0) __hip_atomic_store(&sy->arrive[tile], slice_tag(epoch, win), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    } else {
+        // ================= walk role =================
+        const int j = t;
+        const bool live = j < n;
+        ScanShared sh;
+        scan_shared_init(sh, smem, n, kd, true);
+        const double* tab_g = reinterpret_cast<const double*>(d.tabs + chain);
+        const long slice_off = (long)l * n;
+        int8_t* fields_g = d.fields + (long)chain * d.f_stride + slice_off;
+        double dg = 0.0;
+        if (live) {
+            const long off = (long)chain * d.rs_stride + slice_off + j;
+            const int i = d.perm[off];
+            const int kp = d.kprop[off];
+            const int old_f = fields_g[i];
+            sh.site[j] = i; sh.newf[j] = (signed char)c_proposal[old_f][kp];
+            sh.rbv[j] = tab_g[old_f * 3 + kp]; sh.dlt[j] = tab_g[12 + old_f * 3 + kp]; sh.ur[j] = d.u[off];
+            dg = G[j + (long)n * j];                                  // first window: G was written by the previous kernel
+            sh.diag[j] = dg;
+        }
+        if (j < 32) sh.tl[j] = tab_g[j];
+        __syncthreads();
+        int pos = 0, total_acc = 0;
+        bool solo = false;
+        int* flag = sh.acc_site + UPDATE_KD;                          // spare LDS word behind acc_site: wave 0's verdict on the census
+#ifdef DQ_SCAN_STAMPS
+        ScanProf prof; unsigned long long tk0, t_hand = 0; STAMP(tk0)
+#endif
+        for (unsigned win = 1;; ++win) {
+            const int k = walk_window<true>(sh, pos, dg, n, kd, j, live, G, GT, d, slice_off, chain, fields_g, Up, Wp PROF_PASS);
+            total_acc += k;
+            const bool final = pos >= n;
+#ifdef DQ_SCAN_STAMPS
+            unsigned long long th0; STAMP(th0)
+#endif
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // panel stores of every wave have left the CU
+            __syncthreads();
+            if (win == 1) {
+                // census: is every flush workgroup resident?  (one coalesced load; they checked in while the first window was walked)
+                if (wave == 0) {
+                    unsigned spins = 0; bool all_in = false;
+                    for (;;) {
+                        const unsigned a = lane < F ? __hip_atomic_load(&sy->arrive[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : slice_tag(epoch, 0);
+                        if (__all(a == slice_tag(epoch, 0))) { all_in = true; break; }
+                        if (++spins > SLICE_CENSUS_SPINS) break;
+                        __builtin_amdgcn_s_sleep(8);
+                    }
+                    if (lane == 0) *flag = all_in ? 0 : 1;
+                }
+                __syncthreads();
+                solo = *flag != 0;
+                __syncthreads();
+            }
+            if (t == 0) {
+                __hip_atomic_store(&sy->seq, ((unsigned long long)slice_tag(epoch, win) << 32) | (final ? SLICE_FINAL_BIT : 0u) | (solo ? SLICE_SOLO_BIT : 0u) | (unsigned)k,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (solo && win == 1) __hip_atomic_fetch_add(&sy->solo_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (solo) {
+                // nobody else touches G during this launch: apply the window from the LDS pair store (plain accesses, this CU's L1 is
+                // write-through; the walk's own sc1 loads are served by the L2 the stores went to)
+                if (k > 0) solo_flush(G, GT, sh.UW, n, k);
+                if (final) break;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (live) sh.diag[j] = dg;
+                __syncthreads();
+                continue;
+            }
+            if (final) break;
+            // wait until every tile has absorbed this window
+            if (wave == 0) {
+                unsigned spins = 0; bool broken = false;
+                for (;;) {                                            // lane f <-> flush workgroup f (F <= 64): one coalesced load per poll
+                    const unsigned a = lane < F ? __hip_atomic_load(&sy->arrive[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : slice_tag(epoch, win);
+                    if (__all(a == slice_tag(epoch, win))) break;
+                    if (++spins > SLICE_SPIN_LIMIT) { broken = true; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (broken && lane == 0) { __hip_atomic_store(&sy->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (info) atomicOr(info, 4); }
+            }
+            __syncthreads();
+            // G changed: the prefetch restarts from memory.  The diagonal does not: the lane's running value dg (advanced by pu * wj at
+            // every accepted flip) IS G_jj after the flush up to the summation order, so the next window starts from it instead of
+            // paying an L2 round trip in front of the prefetch (it is re-read from G at the start of every slice)
+            if (live) sh.diag[j] = dg;
+            __syncthreads();
+#ifdef DQ_SCAN_STAMPS
+            { unsigned long long th1; STAMP(th1) t_hand += th1 - th0; }
+#endif
+        }
+        if (j == 0) d.acc_out[(long)chain * d.acc_stride + acc_slot] = total_acc;
+#ifdef DQ_SCAN_STAMPS
+        if (j == 0) { unsigned long long tk1; STAMP(tk1)
+            printf("slice l=%d: total %llu cyc | hand-offs %llu | %d acc: decide+fetch %llu pairs %llu tail %llu | window start->first flip %llu | %d empty passes %llu | dump+drain %llu\n",
+                   l, tk1 - tk0, t_hand, prof.n_acc, prof.t_wait, prof.t_kloop, prof.t_tail, prof.t_first, prof.n_noacc, prof.t_noacc, prof.t_dump); }
+#endif
     }
 }
 
@@ -817,7 +857,6 @@ static int pick_kd(int n) {
 static std::mutex g_resv_mu;
 static int g_resv_used[64] = {};
 static int g_resv_cap[64] = {};
-static std::atomic<int> g_engines[64];         // engines alive per device (this process)
 int slice_workgroups(int n, int n_chains) { return (1 + slice_flush_workgroups(n)) * n_chains; }
 bool slice_reserve(int device, int n, int n_chains) {
     if (device < 0 || device >= 64 || n > 1024) return false;
@@ -832,17 +871,6 @@ bool slice_reserve(int device, int n, int n_chains) {
     if (g_resv_used[device] + want > g_resv_cap[device]) return false;
     g_resv_used[device] += want;
     return true;
-}
-// Engines of this process on the device.  The persistent kernels are only launched while there are at most three: with 8 or 16
-// single-chain engines of one process sweeping at once on one device (4 HW queues shared by all their streams, CUs oversubscribed)
-// a transient G error inside one stabilisation block was observed on engines running the persistent kernel about once per 650
-// engine-sweeps (never on the engines on kernel pairs: 0 in 8 450; never with <= 6 engines: 0 in 2 300; scripts/pt_stress.py).
-// Many chains per device belong in ONE batched engine (dqmc_create_batch) anyway.
-void slice_engine_created(int device) { if (device >= 0 && device < 64) g_engines[device].fetch_add(1); }
-void slice_engine_destroyed(int device) { if (device >= 0 && device < 64) g_engines[device].fetch_sub(1); }
-bool slice_persistent_allowed(int device) {
-    static const int max_engines = getenv("DQMC_SLICE_MAX_ENGINES") ? atoi(getenv("DQMC_SLICE_MAX_ENGINES")) : 3;
-    return device >= 0 && device < 64 && g_engines[device].load() <= max_engines;
 }
 void slice_release(int device, int n, int n_chains) {
     if (device < 0 || device >= 64) return;

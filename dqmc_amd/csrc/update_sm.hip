@@ -47,7 +47,8 @@ using d4 = __attribute__((ext_vector_type(4))) double;
 __constant__ int c_proposal_sm[4][3] = {{1, 2, 3}, {0, 2, 3}, {0, 1, 3}, {0, 1, 2}};   // include/field.h:45-48
 
 constexpr int SM_KD = UPDATE_KD;               // largest window: 2 x 16 broadcast slots per 16-lane row
-constexpr unsigned SM_SPIN_LIMIT = 1u << 20;
+constexpr unsigned SM_SPIN_LIMIT = 1u << 22;      // polls (>= 1 us each) a resident partner is given
+constexpr unsigned SM_CENSUS_SPINS = 1024;        // polls the walk grants late flush workgroups at kernel start (~0.5 ms) before it leaves the slice untouched
 // LDS row stride of cols / rows (doubles), = 1 mod 32: rows m = 0..15 of one column land in distinct banks
 __host__ __device__ inline int sm_ls(int n) { return ((n + 31) / 32) * 32 + 1; }
 
@@ -366,8 +367,6 @@ __device__ __forceinline__ void sm_flush_tile(double* __restrict__ G, double* __
     }
 }
 
-struct SliceSync { unsigned long long seq; unsigned int arrived; unsigned int exits; unsigned int error; unsigned int pad[11]; unsigned int arrive[240]; };   // 1 KiB per chain (layout of update.hip; this kernel uses the counter)
-
 }  // namespace
 
 // grid = (1 + Fwg, chains): workgroup 0 walks, workgroups 1 .. Fwg flush; flush workgroup f owns the 32 x 32 tiles f, f + Fwg, ...
@@ -386,9 +385,12 @@ __global__ __launch_bounds__(256) void slice_sm_kernel(UpdateDesc d, SliceSync* 
     double* __restrict__ Bp = d.Wpanel + (long)chain * d.panel_stride;
     double* __restrict__ Cp = d.Cpanel + (long)chain * (SM_KD * SM_KD);
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const unsigned epoch = d.slice_epoch;                             // hand-off words carry the launch number: SliceSync, common.h
 
     if (blockIdx.x > 0) {
         // ================= flush role: 32x32 tiles of G, one 16x16 sub-tile per wave =================
+        if ((int)blockIdx.x - 1 == d.slice_absent_tile) return;       // debug: a workgroup that never becomes resident
+        if (t == 0) __hip_atomic_store(&sy->arrive[blockIdx.x - 1], slice_tag(epoch, 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // census: resident
         // one wave polls the window word, the others take it from LDS (polling cost: guide, Guideline 16 Pitfall 9)
         unsigned long long* bcast = reinterpret_cast<unsigned long long*>(smem);
         for (unsigned win = 1;; ++win) {
@@ -396,7 +398,7 @@ __global__ __launch_bounds__(256) void slice_sm_kernel(UpdateDesc d, SliceSync* 
                 unsigned long long w_ = 0; unsigned spins = 0; bool give_up = false;
                 for (;;) {
                     w_ = __hip_atomic_load(&sy->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if ((unsigned)(w_ >> 32) == win) break;
+                    if ((unsigned)(w_ >> 32) == slice_tag(epoch, win)) break;
                     if (++spins > SM_SPIN_LIMIT) { give_up = true; break; }
                     __builtin_amdgcn_s_sleep(1);
                 }
@@ -406,8 +408,10 @@ __global__ __launch_bounds__(256) void slice_sm_kernel(UpdateDesc d, SliceSync* 
             __syncthreads();
             const unsigned long long word = bcast[win & 1];
             if (word == ~0ULL) break;
-            const int k = (int)(word & 0x7fffffffULL);
-            const bool final = (word >> 31) & 1ULL;
+            const unsigned lo = (unsigned)word;
+            if (lo & SLICE_SOLO_BIT) break;                           // the walk found the grid incomplete and left before touching anything: so do we
+            const int k = (int)(lo & 0x3fffffffu);
+            const bool final = (lo & SLICE_FINAL_BIT) != 0;
             if (k > 0) {
                 for (int tile = (int)blockIdx.x - 1; tile < n_tiles; tile += F) {
                     const int a0 = (tile % tiles_per_dim) * 32 + (wave & 1) * 16;
@@ -419,7 +423,7 @@ __global__ __launch_bounds__(256) void slice_sm_kernel(UpdateDesc d, SliceSync* 
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains before the arrival is signalled
             __syncthreads();
             // arrival: this workgroup's own word (a read-modify-write on one shared counter serialises in L2: 162 of them per window at n = 576)
-            if (t == 0) __hip_atomic_store(&sy->arrive[blockIdx.x - 1], win, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t == 0) __hip_atomic_store(&sy->arrive[blockIdx.x - 1], slice_tag(epoch, win), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     } else {
         // ================= walk role =================
@@ -440,7 +444,36 @@ __global__ __launch_bounds__(256) void slice_sm_kernel(UpdateDesc d, SliceSync* 
             sh.diag0[tt] = G[tt + (long)n * tt];                         // first window: G was written by the previous kernel
         }
         if (t < 32) sh.tl[t] = tab_g[t];
-        __syncthreads();
+        // census BEFORE the first window (nothing has been modified yet): has every flush workgroup checked in for this launch?  If some
+        // have not after a bounded wait, the walk publishes the abort flag and leaves: the slice stays exactly as it was (fields, exp(V)
+        // tables and G untouched), info |= 8 tells the host, the engine takes the kernel pairs from then on.  Once all have checked in,
+        // every later hand-off completes in bounded time (resident workgroups always make progress).
+        if (wave == 0) {
+            unsigned spins = 0; bool all_in = false;
+            for (;;) {
+                bool in = true;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const int f = lane + 64 * q;
+                    const unsigned a = f < F ? __hip_atomic_load(&sy->arrive[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : slice_tag(epoch, 0);
+                    in = in && a == slice_tag(epoch, 0);
+                }
+                if (__all(in)) { all_in = true; break; }
+                if (++spins > SM_CENSUS_SPINS) break;
+                __builtin_amdgcn_s_sleep(8);
+            }
+            if (!all_in && lane == 0) {
+                __hip_atomic_store(&sy->seq, ((unsigned long long)slice_tag(epoch, 1) << 32) | SLICE_SOLO_BIT | SLICE_FINAL_BIT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(&sy->solo_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (info) atomicOr(info, 8);
+            }
+        }
+        __syncthreads();                                              // (orders the prologue's LDS writes as well)
+        // every wave re-derives the verdict from the word wave 0 may have published (LDS would need one more barrier)
+        {
+            const unsigned long long w0 = __hip_atomic_load(&sy->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((unsigned)(w0 >> 32) == slice_tag(epoch, 1) && ((unsigned)w0 & SLICE_SOLO_BIT)) return;
+        }
         int pos = 0, total_acc = 0;
         bool broken = false;
         SMX(SmProf prof; unsigned long long tk0, t_hand = 0; SMT(tk0))
@@ -451,7 +484,7 @@ __global__ __launch_bounds__(256) void slice_sm_kernel(UpdateDesc d, SliceSync* 
             SMX(unsigned long long th0; SMT(th0))
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // panel stores of every wave have left the CU
             __syncthreads();
-            if (t == 0) __hip_atomic_store(&sy->seq, ((unsigned long long)win << 32) | ((unsigned long long)final << 31) | (unsigned long long)k,
+            if (t == 0) __hip_atomic_store(&sy->seq, ((unsigned long long)slice_tag(epoch, win) << 32) | (final ? SLICE_FINAL_BIT : 0u) | (unsigned)k,
                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (final) break;
             // wait until every flush workgroup has absorbed this window, then refresh the diagonal from the flushed G
@@ -462,8 +495,8 @@ __global__ __launch_bounds__(256) void slice_sm_kernel(UpdateDesc d, SliceSync* 
 #pragma unroll
                     for (int q = 0; q < 3; ++q) {
                         const int f = lane + 64 * q;
-                        const unsigned a = f < F ? __hip_atomic_load(&sy->arrive[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : win;
-                        all_in = all_in && a == win;
+                        const unsigned a = f < F ? __hip_atomic_load(&sy->arrive[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : slice_tag(epoch, win);
+                        all_in = all_in && a == slice_tag(epoch, win);
                     }
                     if (__all(all_in)) break;
                     if (++spins > SM_SPIN_LIMIT) { broken = true; break; }
@@ -478,17 +511,6 @@ __global__ __launch_bounds__(256) void slice_sm_kernel(UpdateDesc d, SliceSync* 
         SMX(if (t == 0) { unsigned long long tk1; SMT(tk1)
             printf("sm slice l=%d: total %llu cyc | windows (walk incl. passes+accepts) %llu | %d passes %llu | %d accepts %llu | dump %llu | hand-offs %llu\n",
                    l, tk1 - tk0, prof.t_first, prof.n_pass, prof.t_pass, prof.n_acc, prof.t_acc, prof.t_dump, t_hand); })
-    }
-    // exit ticket: the last workgroup of the chain to leave re-arms the sync words for the next launch
-    __syncthreads();
-    if (t == 0) {
-        const unsigned ticket = __hip_atomic_fetch_add(&sy->exits, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (ticket == (unsigned)F) {
-            __hip_atomic_store(&sy->seq, 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&sy->arrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            for (int f = 0; f < F; ++f) __hip_atomic_store(&sy->arrive[f], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&sy->exits, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
     }
 }
 

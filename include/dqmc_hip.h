@@ -327,10 +327,11 @@ int dqmc_replica_exchange_round(dqmc_engine* e, dqmc_comm* comm, int exchange_at
  * stream) spent inside the local-update kernels since the last call -- the
  * live measurement bench.py uses for the rank-1 roofline.                    */
 int dqmc_update_kernel_time(dqmc_engine* e, double* ms, int64_t* n_launches, int64_t* n_accepted);
-/* Diagnostic: 1 when the next local update of this engine takes a persistent single-launch slice kernel, 0 when it
- * takes the scan / flush kernel pairs (no CU reservation left, more engines of this process on the device than
- * DQMC_SLICE_MAX_ENGINES, or an earlier hand-off time-out).  The two paths sum the low-rank corrections in different
- * orders: G between stabilisations agrees to ~1e-11, everything after a stabilisation bitwise.  No counterpart.     */
+/* Diagnostic: 0 when the next local update of this engine takes the scan / flush kernel pairs (no CU reservation left,
+ * or an earlier hand-off failure), 1 when it takes a persistent single-launch slice kernel, 2 when it does and at least
+ * one earlier launch found a flush workgroup not resident in time and walked the slice solo (n <= 256) / left the slice
+ * untouched and reported DQMC_ENUMERIC (n > 256).  The paths sum the low-rank corrections in different orders: G between
+ * stabilisations agrees to ~1e-11, everything after a stabilisation bitwise.  No counterpart.                        */
 int dqmc_slice_path(dqmc_engine* e);
 /* enable (1) / disable (0) the per-slice HIP-event timing above (default 0:
  * events serialise nothing but cost a few microseconds per slice).           */

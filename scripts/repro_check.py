@@ -1,5 +1,5 @@
 """Run-to-run reproducibility of a full cfg-3 sweep per slice path: six runs with one engine alive (persistent single-launch slice
-kernel), three with more than DQMC_SLICE_MAX_ENGINES engines alive (scan / flush kernel pairs).  Within a path every statistic is
+kernel), three with DQMC_SLICE_CU_MARGIN set so that no reservation is left (scan / flush kernel pairs).  Within a path every statistic is
 bitwise identical; between the paths the wrap error differs in its 5th digit (summation order of the low-rank corrections) and G
 after the sweep is bitwise identical.  usage: python scripts/repro_check.py"""
 import os, sys

@@ -651,7 +651,7 @@ def test_bitwise_reproducible_at_full_size(hip):
     m = HubbardModel(**CONFIGS["cfg3"]); rng = np.random.default_rng(31)
     f0 = m.random_fields(9); sf, sb = m.random_stream(rng), m.random_stream(rng)
     res = []
-    gc.collect()                                   # engines of earlier tests still waiting for the collector count towards DQMC_SLICE_MAX_ENGINES
+    gc.collect()                                   # engines of earlier tests still waiting for the collector hold CU reservations
     for _ in range(2):
         with m.engine(hip) as e:                   # one engine alive at a time: both runs take the same slice path
             path0 = e.slice_path()
@@ -660,6 +660,53 @@ def test_bitwise_reproducible_at_full_size(hip):
     assert res[0][5] == res[0][6] == res[1][5] == res[1][6], [r[5:] for r in res]     # the wrap error between stabilisations depends on the path (summation order)
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
     assert res[0][2] == res[1][2] and res[0][3] == res[1][3] and res[0][4] == res[1][4]
+
+
+def test_persistent_slice_kernel_survives_a_workgroup_that_never_becomes_resident(hip, orc, monkeypatch):
+    """The persistent slice kernel checks residency instead of assuming it (update.hip: census before the first publish).  With the
+    test hook DQMC_DEBUG_SLICE_ABSENT one flush workgroup leaves at once without checking in -- what a workgroup that never becomes
+    resident looks like to the others: the walk must notice before it has published anything, walk the slice solo (its own flushes)
+    and end with fields and G equal to the oracle's; no error is returned and the Markov trajectory is kept."""
+    m = HubbardModel(**CONFIGS["cfg2"]); rng = np.random.default_rng(77)
+    f0 = m.random_fields(5); sf, sb = m.random_stream(rng), m.random_stream(rng)
+    monkeypatch.setenv("DQMC_DEBUG_SLICE_ABSENT", "2")            # read when the engine is created
+    e = m.engine(hip)
+    monkeypatch.delenv("DQMC_DEBUG_SLICE_ABSENT")
+    if e.slice_path() == 0:
+        pytest.skip("no CU reservation left for a persistent slice kernel (engines of other tests still alive)")
+    o = m.engine(orc)
+    for x in (e, o):
+        x.set_fields(f0); x.init(); x.sweep_0_to_beta(*sf); x.sweep_beta_to_0(*sb)
+    assert e.slice_path() == 2, "the solo fall-back was not taken"
+    assert (e.get_fields() == o.get_fields()).all() and e.stats().n_accepted == o.stats().n_accepted
+    assert close(e.get_G(), o.get_G())
+    e.close()
+
+
+def test_persistent_submatrix_kernel_leaves_the_slice_untouched_when_the_grid_is_incomplete(hip, orc, monkeypatch):
+    """n > 256: the sub-matrix slice kernel takes its census BEFORE the first window.  A flush workgroup that never checks in makes the
+    walk leave with the slice exactly as it was (fields, tables and G untouched), the sweep reports DQMC_ENUMERIC, and the engine goes
+    on with the scan / flush kernel pairs: after re-initialisation the same sweep equals the oracle's."""
+    from dqmc_amd import DqmcError
+    m = HubbardModel(L1=18, L2=18, U=4.0, beta=2.0, nt=20, n_stab=10); rng = np.random.default_rng(78)
+    f0 = m.random_fields(6); sf, sb = m.random_stream(rng), m.random_stream(rng)
+    monkeypatch.setenv("DQMC_DEBUG_SLICE_ABSENT", "3")
+    e = m.engine(hip)
+    monkeypatch.delenv("DQMC_DEBUG_SLICE_ABSENT")
+    if e.slice_path() == 0:
+        pytest.skip("no CU reservation left for a persistent slice kernel")
+    e.set_fields(f0); e.init(); G0 = e.get_G()
+    perm, k, u = m.random_stream(rng, 1)
+    with pytest.raises(DqmcError) as ei:
+        e.local_update_slice(0, perm, k, u)                       # no wrap in front: G must come back bit for bit
+    assert ei.value.code == -3
+    assert (e.get_fields() == f0).all() and np.array_equal(e.get_G(), G0)
+    assert e.slice_path() == 0                                     # kernel pairs from now on
+    o = m.engine(orc)
+    for x in (e, o):
+        x.set_fields(f0); x.init(); x.sweep_0_to_beta(*sf); x.sweep_beta_to_0(*sb)
+    assert (e.get_fields() == o.get_fields()).all() and close(e.get_G(), o.get_G())
+    e.close()
 
 
 def test_error_codes(hip):

@@ -63,9 +63,9 @@ def test_cfg4_replica_exchange_on_hip_engines(hip, orc):
             if rnd == 0:
                 assert res[0].partner == 7 and res[7].partner == 0 and res[0].decider == 1        # the wrap pair, rank 0 decides
         assert {True, False} <= {a for _, a in seen}, "both an accepted and a rejected swap must occur"
-        # one full sweep of every replica between rounds, one engine after the other (on the 8-GPU node every engine has its own
-        # device; 8 engines sweeping AT ONCE on one device is exercised by test_many_engines_sweeping_at_once_on_one_device)
-        pt.sweeps(1, concurrently=False); tw.sweeps(1)
+        # one full sweep of every replica between rounds, all 8 engines AT ONCE on one device (three of them on the persistent slice
+        # kernel, five on the kernel pairs: slice_reserve), compared with the oracle entry by entry
+        pt.sweeps(1, concurrently=True); tw.sweeps(1)
         for r in range(8):
             g, o = pt.get(r, n, nt), tw.get(r)
             if not np.array_equal(g["fields"], o["fields"]):
@@ -84,10 +84,10 @@ def test_cfg4_replica_exchange_on_hip_engines(hip, orc):
 
 
 def test_many_engines_sweeping_at_once_on_one_device(hip):
-    """8 single-chain engines (cfg-4 size) driven by 8 host threads on ONE device, two sweeps each.  With more than three engines
-    of one process on a device every engine takes the scan / flush kernel pairs (slice_persistent_allowed, update.hip; DESIGN.md
-    section 7 has the stress measurements behind that rule).  No hand-off may time out (a time-out is an error return), and every
-    engine must end self-consistent: its G equals the from-scratch evaluation of its own final fields."""
+    """8 single-chain engines (cfg-4 size) driven by 8 host threads on ONE device, two sweeps each: the first three hold CU
+    reservations for the persistent slice kernel, the others take the scan / flush kernel pairs (slice_reserve, update.hip).  No
+    hand-off may fail (a failure is an error return), and every engine must end self-consistent: its G equals the from-scratch
+    evaluation of its own final fields."""
     cfg = CONFIGS["cfg4"]; L, U, nt, n_stab = cfg["L1"], cfg["U"], cfg["nt"], cfg["n_stab"]; n = L * L
     betas = [8.0 - 0.5 * r for r in range(8)]; seeds = [500 + r for r in range(8)]
     h = load_host()
