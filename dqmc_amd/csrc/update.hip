@@ -48,10 +48,12 @@ __device__ __forceinline__ void st_coh(double* p, double x) {
     __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// walk v4's share (walk4.inc: posof[n] | Gs[2][16][17] | Ct[16][16] double2 | dgs[16]), behind the v3 layout
+#define W4_EXTRA(n) ((((size_t)(n) * 4 + 15) & ~(size_t)15) + 2 * 16 * 17 * 8 + 16 * 16 * 16 + 16 * 8)
 // bytes of dynamic LDS: UW[kd][n] | diag, dlt, rbv, ur [n] | tables[32] | site[n] | newf[n] (padded) | (register variant) diag2[n]
 __host__ __device__ inline size_t scan_lds_bytes(int n, int kd, bool regs) {
     const size_t base = (((size_t)16 * kd * n + (size_t)n * 32 + 256 + (size_t)n * 4 + (size_t)n) + 63) & ~(size_t)63;
-    return base + (regs ? (size_t)n * 8 + 4 * (UPDATE_KD + 4) : 0);       // diag2 | acc_site[KD] | 4 spare words (verdicts of the persistent kernel's wave 0)
+    return base + (regs ? (size_t)n * 8 + 4 * (UPDATE_KD + 4) + W4_EXTRA(n) : 0);       // diag2 | acc_site[KD] | 4 spare words (verdicts of the persistent kernel's wave 0)
 }
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a workgroup-scope release fence, which on
@@ -390,6 +392,8 @@ __device__ __forceinline__ int walk_window(const ScanShared& sh, int& pos, doubl
 }
 static_assert(UPDATE_KD == 32, "walk v3 keeps 2 x 16 pending pairs per lane in registers");
 
+#include "walk4.inc"
+
 __device__ __forceinline__ void scan_shared_init(ScanShared& sh, unsigned char* smem, int n, int kd, bool regs) {
     sh.UW = reinterpret_cast<double2*>(smem);
     sh.diag = reinterpret_cast<double*>(sh.UW + (size_t)kd * n);
@@ -459,8 +463,13 @@ __global__ __launch_bounds__(MAXT) void scan_kernel(UpdateDesc d, int l, int acc
 #endif
     if constexpr (REGS) {
         const double* __restrict__ GT = d.GT.at(chain);
+#ifdef DQ_WALK_V3
         double dg0 = live ? sh.diag[j] : 0.0;
         k = walk_window<false>(sh, pos, dg0, n, kd, j, live, G, GT, d, slice_off, chain, fields_g, Up, Wp PROF_PASS);
+#else
+        Walk4Shared w4; walk4_shared_init(w4, smem + scan_lds_bytes(n, kd, true) - W4_EXTRA(n), n);
+        k = walk_window4<false>(sh, w4, pos, n, kd, j, live, G, GT, d, slice_off, chain, fields_g, Up, Wp);
+#endif
     } else {
         double pcA[SCAN_PF], prA[SCAN_PF], pcB[SCAN_PF], prB[SCAN_PF];
         int g = pos / SCAN_PF;
@@ -711,11 +720,18 @@ __global__ __launch_bounds__(256) void slice_kernel(UpdateDesc d, SliceSync* syn
         int pos = 0, total_acc = 0;
         bool solo = false;
         int* flag = sh.acc_site + UPDATE_KD;                          // spare LDS word behind acc_site: wave 0's verdict on the census
+#ifndef DQ_WALK_V3
+        Walk4Shared w4; walk4_shared_init(w4, smem + scan_lds_bytes(n, kd, true) - W4_EXTRA(n), n);
+#endif
 #ifdef DQ_SCAN_STAMPS
         ScanProf prof; unsigned long long tk0, t_hand = 0; STAMP(tk0)
 #endif
         for (unsigned win = 1;; ++win) {
+#ifdef DQ_WALK_V3
             const int k = walk_window<true>(sh, pos, dg, n, kd, j, live, G, GT, d, slice_off, chain, fields_g, Up, Wp PROF_PASS);
+#else
+            const int k = walk_window4<true>(sh, w4, pos, n, kd, j, live, G, GT, d, slice_off, chain, fields_g, Up, Wp);
+#endif
             total_acc += k;
             const bool final = pos >= n;
 #ifdef DQ_SCAN_STAMPS
@@ -821,8 +837,15 @@ __global__ __launch_bounds__(256) void slice_solo_kernel(UpdateDesc d, int l, in
 #ifdef DQ_SCAN_STAMPS
     ScanProf prof;
 #endif
+#ifndef DQ_WALK_V3
+    Walk4Shared w4; walk4_shared_init(w4, smem + scan_lds_bytes(n, kd, true) - W4_EXTRA(n), n);
+#endif
     for (;;) {
+#ifdef DQ_WALK_V3
         const int k = walk_window<false, false>(sh, pos, dg, n, kd, j, live, G, GT, d, slice_off, chain, fields_g, nullptr, nullptr PROF_PASS);
+#else
+        const int k = walk_window4<false, false>(sh, w4, pos, n, kd, j, live, G, GT, d, slice_off, chain, fields_g, nullptr, nullptr);
+#endif
         total_acc += k;
         __syncthreads();                                              // every pair of the window is in LDS
         if (k > 0) {
