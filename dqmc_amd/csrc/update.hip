@@ -48,12 +48,10 @@ __device__ __forceinline__ void st_coh(double* p, double x) {
     __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// walk v4's share (walk4.inc: posof[n] | Gs[2][16][17] | Ct[16][16] double2 | dgs[16]), behind the v3 layout
-#define W4_EXTRA(n) ((((size_t)(n) * 4 + 15) & ~(size_t)15) + 2 * 16 * 17 * 8 + 16 * 16 * 16 + 16 * 8)
 // bytes of dynamic LDS: UW[kd][n] | diag, dlt, rbv, ur [n] | tables[32] | site[n] | newf[n] (padded) | (register variant) diag2[n]
 __host__ __device__ inline size_t scan_lds_bytes(int n, int kd, bool regs) {
     const size_t base = (((size_t)16 * kd * n + (size_t)n * 32 + 256 + (size_t)n * 4 + (size_t)n) + 63) & ~(size_t)63;
-    return base + (regs ? (size_t)n * 8 + 4 * (UPDATE_KD + 4) + W4_EXTRA(n) : 0);       // diag2 | acc_site[KD] | 4 spare words (verdicts of the persistent kernel's wave 0)
+    return base + (regs ? (size_t)n * 8 + 4 * (UPDATE_KD + 4) : 0);       // diag2 | acc_site[KD] | 4 spare words (verdicts of the persistent kernel's wave 0)
 }
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a workgroup-scope release fence, which on
@@ -392,7 +390,128 @@ __device__ __forceinline__ int walk_window(const ScanShared& sh, int& pos, doubl
 }
 static_assert(UPDATE_KD == 32, "walk v3 keeps 2 x 16 pending pairs per lane in registers");
 
-#include "walk4.inc"
+// ---- walk v6: v3's structure, pending pairs and prefetch sets in a hand-managed register file ------------------------------------
+// Stamps and the ISA of v3 and of an intermediate version with compiler-managed scalars (round 3): of ~2 400 clk per
+// accepted flip ~300 went into writing the new pair into a dynamically indexed register slot, ~120 into FMAs on padded octets and
+// their masking selects, ~150 into an IEEE division that the compiler had sunk behind the decision; with 64 named scalars and a
+// dispatch on K instead, the allocator's reconciliation moves at the joins cost ~1 000 clk per flip.  Here
+//   * the pairs and the three prefetch sets live in registers the allocator never sees (walk_bodies.inc, generated: literal
+//     register names, kernels compiled with amdgpu_num_vgpr(64));
+//   * the accepted-flip body exists once per pending-pair count K = 0..31: exactly 2K DPP FMAs, the new pair is two moves;
+//   * the pivot's two prefetched G elements are picked lazily, on acceptance only, by an if / else tree over (set, proposal)
+//     behind a counted s_waitcnt vmcnt(32) (the two younger groups' 32 loads may still be in flight);
+//   * pref = delta / r (source/model.cpp:132) is formed BEFORE the ballot from v_rcp_f64 + two Newton steps + one residual
+//     correction, interleaved with the decision chain instead of behind it.
+// Everything else -- decisions for 8 proposals at once, prefetch three groups deep, double-buffered diagonal, one LDS barrier
+// per accepted flip, no global store inside the walk -- is v3's.
+#include "walk_bodies.inc"
+#pragma clang diagnostic ignored "-Winline-asm"
+
+// issues the loads of the 8 proposals of group g into prefetch set gs = g % 3 (AGPRs; nothing waits here).  Addresses: the column
+// base G + n * site * 8 is wave-uniform (scalar ALU, from one lane-distributed LDS read of the group's sites), the lane adds j * 8.
+template <bool COH>
+__device__ __forceinline__ void walk6_load_group(const double* __restrict__ G, const double* __restrict__ GT, const ScanShared& sh, int g, int gs, int n, int j, bool live) {
+    const unsigned jj8 = (unsigned)(live ? j : n - 1) * 8u;
+    const int ig = sh.site[min(g * 8 + (int)(threadIdx.x & 7), n - 1)];       // lane q (mod 8): site of proposal 8 g + q, clamped: loads stay unconditional
+    const char* gcol[8]; const char* tcol[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const size_t off = (size_t)((unsigned)__builtin_amdgcn_readlane(ig, q) * (unsigned)n) * 8u;
+        gcol[q] = reinterpret_cast<const char*>(G) + off; tcol[q] = reinterpret_cast<const char*>(GT) + off;
+    }
+    if (gs == 0) { if (COH) { DQ_W6_LOADSET_0_COH } else { DQ_W6_LOADSET_0_PLAIN } }
+    else if (gs == 1) { if (COH) { DQ_W6_LOADSET_1_COH } else { DQ_W6_LOADSET_1_PLAIN } }
+    else { if (COH) { DQ_W6_LOADSET_2_COH } else { DQ_W6_LOADSET_2_PLAIN } }
+}
+
+template <bool COH, bool PANELS = true>
+__device__ __forceinline__ int walk_window6(const ScanShared& sh, int& pos, double& dg, int n, int kd, int j, bool live, const double* __restrict__ G,
+                                            const double* __restrict__ GT, const UpdateDesc& d, long slice_off, int chain, int8_t* fields_g,
+                                            double* __restrict__ Up, double* __restrict__ Wp PROF_ARG) {
+    const int lane = threadIdx.x & 63, r16 = lane & 15, q8 = lane & 7;
+    DQ_W6_RESERVE;
+    int par = 0, k = 0;
+    int g = pos >> 3;
+    bool done = false;
+    // no vector-memory operation of this workgroup may be in flight when the counted waits below start counting
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    walk6_load_group<COH>(G, GT, sh, g, g % 3, n, j, live);
+    walk6_load_group<COH>(G, GT, sh, g + 1, (g + 1) % 3, n, j, live);
+#ifdef DQ_SCAN_STAMPS
+#define DQ_ST(...) __VA_ARGS__
+#else
+#define DQ_ST(...)
+#endif
+    while (!done) {
+        DQ_ST(unsigned long long tg0, tg1; STAMP(tg0))
+        const int gs = g % 3;                                                  // register set of this group
+        walk6_load_group<COH>(G, GT, sh, g + 2, (g + 2) % 3, n, j, live);
+        DQ_ST(STAMP(tg1) prof.t_first += tg1 - tg0;)
+        const int gbase = g * 8;
+        // what lane q needs to decide proposal gbase + q is read once per group; only the diagonal changes between passes
+        const int p_l = gbase + q8, pc_l = min(p_l, n - 1);
+        const int i_l = sh.site[pc_l];
+        const double dl_l = sh.dlt[pc_l], rb_l = sh.rbv[pc_l], ur_l = sh.ur[pc_l];
+        for (;;) {
+            DQ_ST(unsigned long long t0, t1, t2, t3; STAMP(t0))
+            // decisions for the (remaining) proposals of the group under the current diagonal: lane q <-> proposal gbase + q
+            const double* dcur = par ? sh.diag2 : sh.diag;
+            const double r_l = 1.0 + (1.0 - dcur[i_l]) * dl_l;                  // det ratio per flavour (source/model.cpp:95)
+            // pref = delta / r (source/model.cpp:132) for every candidate, ahead of the decision
+            double y_ = __builtin_amdgcn_rcp(r_l);
+            double e_ = __builtin_fma(-r_l, y_, 1.0); y_ = __builtin_fma(y_, e_, y_);
+            e_ = __builtin_fma(-r_l, y_, 1.0); y_ = __builtin_fma(y_, e_, y_);
+            double pref_l = dl_l * y_;
+            pref_l = __builtin_fma(__builtin_fma(-r_l, pref_l, dl_l), y_, pref_l);
+            const double R_l = rb_l * (r_l * r_l);                               // :121
+            asm volatile("" : "+v"(pref_l));                                     // keeps the quotient in front of the branch
+            // bernoulli(min(1,|R|)): u < p (source/update.cpp:24, include/utility.h:34-37)
+            const bool acc_l = p_l >= pos && p_l < n && ur_l < fmin(1.0, fabs(R_l));
+            const unsigned bal = (unsigned)__ballot(acc_l) & 0xffu;
+            if (bal == 0u) { pos = min(gbase + 8, n); DQ_ST(STAMP(t1) prof.t_noacc += t1 - t0; prof.n_noacc++;) break; }   // the rest of the group is rejected
+            const int first = __ffs((int)bal) - 1;
+            const int p = gbase + first;
+            pos = p + 1;
+            const int i = __builtin_amdgcn_readlane(i_l, first);
+            const double pref = readlane_f64(pref_l, first);
+            // the pivot's G column / row elements from set gs: this group's 16 loads are done once at most the 32 younger ones are pending
+            int ulo, uhi, wlo, whi;
+            asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+            if (gs == 0) { DQ_W6_PICK_0 } else if (gs == 1) { DQ_W6_PICK_1 } else { DQ_W6_PICK_2 }
+            double uj = __hiloint2double(uhi, ulo), wj = __hiloint2double(whi, wlo);
+            DQ_ST(STAMP(t1))
+            int jv = j, r16v = r16;
+            asm volatile("" : "+v"(jv), "+v"(r16v));                             // see walk_bodies.inc: keeps the bodies' address arithmetic inside them
+            DQ_W6_BODIES
+            DQ_ST(STAMP(t2))
+            ++k; par ^= 1;
+            lds_barrier();
+            DQ_ST(STAMP(t3) prof.t_wait += t1 - t0; prof.t_kloop += t2 - t1; prof.t_tail += t3 - t2; prof.n_acc++;)
+            if (k >= kd) { done = true; break; }
+        }
+        if (pos >= n) done = true;
+        ++g;
+    }
+#undef DQ_ST
+#ifdef DQ_SCAN_STAMPS
+    unsigned long long td0; STAMP(td0)
+#endif
+    // the prefetch loads still in flight must not land in a later window's (or the solo flush's) registers
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // ---- window end: the flush's operands and the accepted field changes leave the workgroup (coalesced, from registers) ----
+    if (PANELS && live) DQ_W6_DUMP;
+    if (j < k) {
+        const int p = sh.acc_site[j];
+        const int i = sh.site[p], new_f = sh.newf[p];
+        fields_g[i] = (int8_t)new_f;                                        // field.set_single_field (source/update.cpp:28)
+        d.expv[(long)chain * d.v_stride + slice_off + i] = sh.tl[24 + new_f];
+        d.invexpv[(long)chain * d.v_stride + slice_off + i] = sh.tl[28 + new_f];
+    }
+#ifdef DQ_SCAN_STAMPS
+    { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); unsigned long long td1; STAMP(td1) prof.t_dump += td1 - td0; }
+#endif
+    return k;
+}
 
 __device__ __forceinline__ void scan_shared_init(ScanShared& sh, unsigned char* smem, int n, int kd, bool regs) {
     sh.UW = reinterpret_cast<double2*>(smem);
@@ -406,7 +525,7 @@ __device__ __forceinline__ void scan_shared_init(ScanShared& sh, unsigned char* 
 // MAXT: the launch bound.  For n <= 256 the kernel runs one wave per SIMD and may use the whole 512-entry register
 // file (walk v3); under a 1024-thread bound (128 VGPRs) only the LDS variant fits.
 template <int MAXT>
-__global__ __launch_bounds__(MAXT) void scan_kernel(UpdateDesc d, int l, int acc_slot, int first, int kd) {
+__global__ __launch_bounds__(MAXT) __attribute__((amdgpu_num_vgpr(64))) void scan_kernel(UpdateDesc d, int l, int acc_slot, int first, int kd) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int chain = blockIdx.y;
     const int n = d.n;
@@ -467,8 +586,8 @@ __global__ __launch_bounds__(MAXT) void scan_kernel(UpdateDesc d, int l, int acc
         double dg0 = live ? sh.diag[j] : 0.0;
         k = walk_window<false>(sh, pos, dg0, n, kd, j, live, G, GT, d, slice_off, chain, fields_g, Up, Wp PROF_PASS);
 #else
-        Walk4Shared w4; walk4_shared_init(w4, smem + scan_lds_bytes(n, kd, true) - W4_EXTRA(n), n);
-        k = walk_window4<false>(sh, w4, pos, n, kd, j, live, G, GT, d, slice_off, chain, fields_g, Up, Wp);
+        double dg0 = live ? sh.diag[j] : 0.0;
+        k = walk_window6<false>(sh, pos, dg0, n, kd, j, live, G, GT, d, slice_off, chain, fields_g, Up, Wp PROF_PASS);
 #endif
     } else {
         double pcA[SCAN_PF], prA[SCAN_PF], pcB[SCAN_PF], prB[SCAN_PF];
@@ -646,7 +765,7 @@ __device__ __attribute__((noinline)) void solo_flush(double* G, double* GT, cons
 constexpr unsigned SLICE_SPIN_LIMIT = 1u << 22;     // polls (>= 1 us each) a resident partner is given
 constexpr unsigned SLICE_CENSUS_SPINS = 256;        // polls the walk grants late flush workgroups before it goes solo (~100-200 us)
 
-__global__ __launch_bounds__(256) void slice_kernel(UpdateDesc d, SliceSync* sync_p, int l, int acc_slot, int kd, int tiles_per_dim, int* info) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(64))) void slice_kernel(UpdateDesc d, SliceSync* sync_p, int l, int acc_slot, int kd, int tiles_per_dim, int* info) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int chain = blockIdx.y;
     const int n = d.n;
@@ -720,9 +839,6 @@ __global__ __launch_bounds__(256) void slice_kernel(UpdateDesc d, SliceSync* syn
         int pos = 0, total_acc = 0;
         bool solo = false;
         int* flag = sh.acc_site + UPDATE_KD;                          // spare LDS word behind acc_site: wave 0's verdict on the census
-#ifndef DQ_WALK_V3
-        Walk4Shared w4; walk4_shared_init(w4, smem + scan_lds_bytes(n, kd, true) - W4_EXTRA(n), n);
-#endif
 #ifdef DQ_SCAN_STAMPS
         ScanProf prof; unsigned long long tk0, t_hand = 0; STAMP(tk0)
 #endif
@@ -730,7 +846,7 @@ __global__ __launch_bounds__(256) void slice_kernel(UpdateDesc d, SliceSync* syn
 #ifdef DQ_WALK_V3
             const int k = walk_window<true>(sh, pos, dg, n, kd, j, live, G, GT, d, slice_off, chain, fields_g, Up, Wp PROF_PASS);
 #else
-            const int k = walk_window4<true>(sh, w4, pos, n, kd, j, live, G, GT, d, slice_off, chain, fields_g, Up, Wp);
+            const int k = walk_window6<true>(sh, pos, dg, n, kd, j, live, G, GT, d, slice_off, chain, fields_g, Up, Wp PROF_PASS);
 #endif
             total_acc += k;
             const bool final = pos >= n;
@@ -796,14 +912,17 @@ __global__ __launch_bounds__(256) void slice_kernel(UpdateDesc d, SliceSync* syn
         if (j == 0) d.acc_out[(long)chain * d.acc_stride + acc_slot] = total_acc;
 #ifdef DQ_SCAN_STAMPS
         if (j == 0) { unsigned long long tk1; STAMP(tk1)
+#if 1
             printf("slice l=%d: total %llu cyc | hand-offs %llu | %d acc: decide+fetch %llu pairs %llu tail %llu | window start->first flip %llu | %d empty passes %llu | dump+drain %llu\n",
-                   l, tk1 - tk0, t_hand, prof.n_acc, prof.t_wait, prof.t_kloop, prof.t_tail, prof.t_first, prof.n_noacc, prof.t_noacc, prof.t_dump); }
+                   l, tk1 - tk0, t_hand, prof.n_acc, prof.t_wait, prof.t_kloop, prof.t_tail, prof.t_first, prof.n_noacc, prof.t_noacc, prof.t_dump);
+#endif
+        }
 #endif
     }
 }
 
 // resume = 1: finish a slice that scan / flush kernel pairs have walked up to state[0] (exits at once when nothing is left)
-__global__ __launch_bounds__(256) void slice_solo_kernel(UpdateDesc d, int l, int acc_slot, int kd, int resume) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(64))) void slice_solo_kernel(UpdateDesc d, int l, int acc_slot, int kd, int resume) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int chain = blockIdx.y;
     const int n = d.n;
@@ -837,14 +956,11 @@ __global__ __launch_bounds__(256) void slice_solo_kernel(UpdateDesc d, int l, in
 #ifdef DQ_SCAN_STAMPS
     ScanProf prof;
 #endif
-#ifndef DQ_WALK_V3
-    Walk4Shared w4; walk4_shared_init(w4, smem + scan_lds_bytes(n, kd, true) - W4_EXTRA(n), n);
-#endif
     for (;;) {
 #ifdef DQ_WALK_V3
         const int k = walk_window<false, false>(sh, pos, dg, n, kd, j, live, G, GT, d, slice_off, chain, fields_g, nullptr, nullptr PROF_PASS);
 #else
-        const int k = walk_window4<false, false>(sh, w4, pos, n, kd, j, live, G, GT, d, slice_off, chain, fields_g, nullptr, nullptr);
+        const int k = walk_window6<false, false>(sh, pos, dg, n, kd, j, live, G, GT, d, slice_off, chain, fields_g, nullptr, nullptr PROF_PASS);
 #endif
         total_acc += k;
         __syncthreads();                                              // every pair of the window is in LDS
