@@ -210,6 +210,44 @@ def replica_exchange_check(lib, eng, d, rounds=2, timeout_s=120.0):
     return out
 
 
+def cfg5_block(lib, device):
+    """BASELINE.json configs[4] (24x24 Hubbard, beta = 10, Ltau = 400, n_stab = 10) in the driver-observed line: from the seeded i.i.d.
+    fields of the golden fixture, init + 1 warm-up sweep + 2 timed sweeps of one chain.  Reported beside the headline, never as
+    `value`.  The roofline row is the same as the headline's: 16 N^2 algorithmic bytes per accepted flip over the HIP-event time of
+    the local-update launches (slice_sm_kernel: the sub-matrix walk + flush roles)."""
+    import dqmc_amd
+    m = dqmc_amd.HubbardModel(**dqmc_amd.CONFIGS["cfg5"])
+    gold = os.path.join(ROOT, "tests", "golden", "cfg5_random_init.npz")
+    fields = np.load(gold)["fields"] if os.path.exists(gold) else m.random_fields(55)
+    e = m.engine(lib, device=device); e.set_fields(fields); e.init()
+    rng = np.random.default_rng(555)
+
+    def sw():
+        e.sweep_0_to_beta(*m.random_stream(rng)); e.sweep_beta_to_0(*m.random_stream(rng))
+    sw(); e.sync()
+    s0 = e.stats()
+    e.set_profiling(True); e.update_kernel_time()
+    steps = 2
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        sw()
+    e.sync()
+    dt = time.perf_counter() - t0
+    ms, launches, acc = e.update_kernel_time(); e.set_profiling(False)
+    s1 = e.stats()
+    n = m.n
+    bpl = 16.0 * n * n * acc / max(1, launches); avg = (ms * 1e-3) / max(1, launches)
+    rec = {"workload": f"cfg5: {m.L1}x{m.L2} Hubbard U={m.U} beta={m.beta} Ltau={m.nt} n_stab={m.n_stab}, one chain, start = i.i.d. fixture fields + 1 warm-up sweep",
+           "value": steps / dt, "unit": "sweeps/s", "ms_per_step": 1e3 * dt / steps, "steps": steps,
+           "acceptance": (s1.n_accepted - s0.n_accepted) / max(1, s1.n_proposed - s0.n_proposed), "max_wrap_err": s1.max_err,
+           "slice_path": e.slice_path(),
+           "roofline": {"kernel": "slice_sm_kernel (sub-matrix walk + flush roles)", "bound": "hbm", "algorithmic_bytes_per_launch": bpl, "avg_launch_ms": avg * 1e3,
+                        "achieved": bpl / avg / 1e9 if avg > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (bpl / avg / 1e9 / HBM_PEAK_GBS) if avg > 0 else 0.0,
+                        "launches": launches, "accepted": acc}}
+    e.close()
+    return rec
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -232,6 +270,7 @@ def main():
     ap.add_argument("--checkerboard", action="store_true",
                     help="opt-in: checkerboard break-up of exp(-dtau K) (dqmc_set_checkerboard) instead of the reference's dense exponential -- a "
                          "different discretisation, reported with \"kinetic\": \"checkerboard\" and never comparable with the headline line")
+    ap.add_argument("--no-cfg5", action="store_true", help="skip the BASELINE.json configs[4] block (24x24, Ltau = 400: init + 1 warm-up + 2 timed sweeps, ~5 s) of the N = 1 line")
     ap.add_argument("--no-replica-exchange", action="store_true", help="skip the RCCL replica-exchange rounds after the timed region (N > 1)")
     args = ap.parse_args()
 
@@ -383,6 +422,8 @@ def main():
             out["batched"] = {"chains_per_gpu": B, "engines": E, "value": B * nb / tb, "unit": "sweeps/s", "ms_per_step": 1e3 * tb / nb, "steps": nb,
                               "note": "aggregate over independent chains sharing kernel launches; not the headline config"}
             for (ee, _, _) in engs: ee.close()
+        if world == 1 and C == 1 and args.config == "cfg3" and not args.checkerboard and not args.no_cfg5:
+            out["cfg5"] = cfg5_block(lib, local_rank)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model, 12345, args.cpu_budget, lib, local_rank, args.config)
         if args.rehearse_shared_gpu:

@@ -65,7 +65,7 @@ struct Ctx {
     int* qabort = nullptr;                     // cooperative QRCP abort words: C
     double* tinv = nullptr;                    // Gauss-Jordan panel inverses: 2048 * C
     double* trinv = nullptr;                   // blocked triangular solve: inverses of the 16 x 16 diagonal blocks, 16 * (n + 16) * C
-    bool use_tri = false;                      // R^-1 D by tri_solve.hip (n <= 640; DQMC_TRI_CLASSIC=1 keeps the per-column substitution)
+    bool use_tri = false;                      // R^-1 D by tri_solve.hip (n <= 640; the per-column substitution of lu.hip above that)
     bool use_gj = false;                       // n <= 256, few chains: solves go through lu_gj.hip (DQMC_LU_CLASSIC=1 keeps dgetrf + dgetrs)
 
     Mat T(int k) const { return Mat{pool + (long)k * C * nn, nn}; }
@@ -90,7 +90,7 @@ struct Ctx {
         DQ_HIP(hipMalloc(&qabort, sizeof(int) * C));
         DQ_HIP(hipMalloc(&tinv, sizeof(double) * 2048 * C));
         DQ_HIP(hipMalloc(&trinv, sizeof(double) * 16 * (n + 16) * C));
-        use_tri = n <= 640 && getenv("DQMC_TRI_CLASSIC") == nullptr;     // any number of chains (128 chains at cfg 3: 432.9 against 437.3 ms per step)
+        use_tri = n <= 640;     // any number of chains (128 chains at cfg 3: 432.9 against 437.3 ms per step)
         // latency regime only: with many chains per launch the blocked LU + per-column substitution has the higher throughput
         // (128 chains, cfg 3: 458 ms per step against 483 ms with the single-wave panels)
         const int gj_max_chains = getenv("DQMC_GJ_MAX_CHAINS") ? atoi(getenv("DQMC_GJ_MAX_CHAINS")) : 8;

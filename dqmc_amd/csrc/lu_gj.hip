@@ -451,14 +451,11 @@ int launch_gj_solve(Mat A, Mat B, Mat X, Mat SA, double* tinv, int* perm, long p
     if (n > 1024) { set_error("gj_solve supports n <= 1024"); return -1; }
     for (int k0 = 0; k0 < n; k0 += GJ_NB) {
         const dim3 pg(1, n_chains);
-        static const bool one_wave = getenv("DQMC_GJ_PANEL_1W") != nullptr;      // A/B switch: the single-wave panel
         const dim3 pb(((n + 63) / 64) * 64);
         if (n > 640) hipLaunchKernelGGL((gj_panel_mw_kernel<16>), pg, pb, 0, s, CMat(A), rowpos, rowpos_stride, perm, perm_stride, tinv, logabsdet, accumulate_logdet, info, n, k0);
         else if (n > 256) hipLaunchKernelGGL((gj_panel_mw_kernel<10>), pg, pb, 0, s, CMat(A), rowpos, rowpos_stride, perm, perm_stride, tinv, logabsdet, accumulate_logdet, info, n, k0);
-        else if (!one_wave && n > 64) hipLaunchKernelGGL((gj_panel_mw_kernel<4>), pg, pb, 0, s, CMat(A), rowpos, rowpos_stride, perm, perm_stride, tinv, logabsdet, accumulate_logdet, info, n, k0);
-        else if (n <= 64) hipLaunchKernelGGL((gj_panel_kernel<1>), pg, dim3(64), 0, s, CMat(A), rowpos, rowpos_stride, perm, perm_stride, tinv, logabsdet, accumulate_logdet, info, n, k0);
-        else if (n <= 128) hipLaunchKernelGGL((gj_panel_kernel<2>), pg, dim3(64), 0, s, CMat(A), rowpos, rowpos_stride, perm, perm_stride, tinv, logabsdet, accumulate_logdet, info, n, k0);
-        else hipLaunchKernelGGL((gj_panel_kernel<4>), pg, dim3(64), 0, s, CMat(A), rowpos, rowpos_stride, perm, perm_stride, tinv, logabsdet, accumulate_logdet, info, n, k0);
+        else if (n > 64) hipLaunchKernelGGL((gj_panel_mw_kernel<4>), pg, pb, 0, s, CMat(A), rowpos, rowpos_stride, perm, perm_stride, tinv, logabsdet, accumulate_logdet, info, n, k0);
+        else hipLaunchKernelGGL((gj_panel_kernel<1>), pg, dim3(64), 0, s, CMat(A), rowpos, rowpos_stride, perm, perm_stride, tinv, logabsdet, accumulate_logdet, info, n, k0);      // n <= 64: one wave holds every row
         const int nbw = n - k0 < GJ_NB ? n - k0 : GJ_NB;
         const int nA = (n + 31) / 32, nS = k0 / 32;
         const int nCA = (n - k0 - nbw + 31) / 32, nCB = (n + 31) / 32;

@@ -323,8 +323,7 @@ __global__ __launch_bounds__(256) void formq_blocked_kernel(CMat Am, const doubl
 }
 
 static bool formq_blocked_ok(int n) {
-    static const bool off = getenv("DQMC_FORMQ_CLASSIC") != nullptr;     // A/B switch
-    return !off && (n == 16 || n == 32 || n == 64 || n == 128 || n == 256 || n == 576);      // NRR = n / 16 exactly: no row bound checks in the kernel
+    return (n == 16 || n == 32 || n == 64 || n == 128 || n == 256 || n == 576);      // NRR = n / 16 exactly: no row bound checks in the kernel
 }
 static void launch_formq_blocked(CMat A, const QrWork& w, Mat L, int n, int n_chains, hipStream_t s) {
     const dim3 grid(n / 16, n_chains), block(256);

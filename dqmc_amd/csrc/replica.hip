@@ -221,32 +221,41 @@ int dqmc_replica_exchange_round(dqmc_engine* e, dqmc_comm* c, int exchange_attem
     }
     if (c->rccl && !c->dbuf) { set_error("replica exchange: communicator has no device scratch"); return DQMC_EINVAL; }
     hipStream_t s = v.stream;
+    // A step that fails on THIS rank (a breakdown in dqmc_init on the trial fields, say) must not leave the partner blocked in its
+    // next receive: local failures are remembered, the remaining messages are still exchanged and carry a status word, both ranks
+    // treat the round as rejected (own fields restored) and both return an error.  A failure of the transport itself ends the
+    // round at once; on the RCCL transport the communicator is aborted so that the peer's pending receive returns.
+    int lrc = 0; std::string lmsg;
+    auto local = [&](int rc) { if (rc != 0 && lrc == 0) { lrc = rc; lmsg = dqmc_last_error(); } return rc; };
+    auto wire = [&](int rc) {
+        if (rc != 0 && c->rccl && c->nc) { (void)ncclCommAbort(c->nc); c->nc = nullptr; }
+        return rc;
+    };
     // --- field exchange (MPI_Sendrecv tag 0, source/update.cpp:59-69) ---
     DQ_TRY_RC(dqmc_sync(e));                                                       // the sweep that precedes the round has finished
     DQ_HIP(hipMemcpyAsync(c->f_mine, v.fields, bytes, hipMemcpyDeviceToDevice, s));
-    DQ_TRY_RC(p2p(c, c->f_mine, c->f_theirs, bytes, partner, 0, s));
+    DQ_TRY_RC(wire(p2p(c, c->f_mine, c->f_theirs, bytes, partner, 0, s)));
     // --- S_r({s}_r), then the trial state on the partner's fields: S_r({s}_partner) (:72-81) ---
-    DQ_TRY_RC(dqmc_global_action(e, &res->S));
+    local(dqmc_global_action(e, &res->S));
     DQ_HIP(hipMemcpyAsync(v.fields, c->f_theirs, bytes, hipMemcpyDeviceToDevice, s));
-    DQ_TRY_RC(engine_fields_changed(e));
-    DQ_TRY_RC(dqmc_init(e));
-    DQ_TRY_RC(dqmc_global_action(e, &res->S_prime));
-    // --- the cross actions (tags 1 and 2, :83-90), one message of two doubles ---
-    const double mine[2] = {res->S_prime, res->S};
-    double theirs[2] = {0.0, 0.0};
-    DQ_TRY_RC(p2p_host(c, mine, theirs, 2, partner, 1, s));
+    if (local(engine_fields_changed(e)) == 0 && local(dqmc_init(e)) == 0) local(dqmc_global_action(e, &res->S_prime));
+    // --- the cross actions (tags 1 and 2, :83-90) and this rank's status, one message of three doubles ---
+    const double mine[3] = {res->S_prime, res->S, lrc ? 1.0 : 0.0};
+    double theirs[3] = {0.0, 0.0, 0.0};
+    DQ_TRY_RC(wire(p2p_host(c, mine, theirs, 3, partner, 1, s)));
     res->S_prime_partner = theirs[0]; res->S_partner = theirs[1];
+    const bool broken = lrc != 0 || theirs[2] != 0.0;
     // --- decision by the lower rank (:92-105) ---
     double flag_mine = 0.0, flag_theirs = 0.0;
     if (rank < partner) {
         res->deltaS = (res->S_prime + res->S_prime_partner) - (res->S + res->S_partner);
         const double metropolis_p = std::fmin(1.0, std::exp(-res->deltaS));
-        res->accepted = (u < metropolis_p) ? 1 : 0;                                // rng.bernoulli(p), include/utility.h:34-37
+        res->accepted = (!broken && u < metropolis_p) ? 1 : 0;                     // rng.bernoulli(p), include/utility.h:34-37
         flag_mine = res->accepted ? 1.0 : 0.0;
     }
-    DQ_TRY_RC(p2p_host(c, &flag_mine, &flag_theirs, 1, partner, 3, s));
+    DQ_TRY_RC(wire(p2p_host(c, &flag_mine, &flag_theirs, 1, partner, 3, s)));
     if (rank > partner) {
-        res->accepted = flag_theirs != 0.0 ? 1 : 0;
+        res->accepted = (!broken && flag_theirs != 0.0) ? 1 : 0;
         res->deltaS = (res->S_prime + res->S_prime_partner) - (res->S + res->S_partner);   // informational: the decider's is the one that counts
     }
     // --- rejected: restore the own fields and re-initialise (:108-115) ---
@@ -255,6 +264,8 @@ int dqmc_replica_exchange_round(dqmc_engine* e, dqmc_comm* c, int exchange_attem
         DQ_TRY_RC(engine_fields_changed(e));
         DQ_TRY_RC(dqmc_init(e));
     }
+    if (lrc != 0) { set_error("replica exchange: " + lmsg + " (round treated as rejected on both ranks, own fields restored)"); return lrc; }
+    if (broken) { set_error("replica exchange: the partner rank reported a failure during the round (treated as rejected, own fields restored)"); return DQMC_ENUMERIC; }
     return 0;
 }
 

@@ -16,6 +16,7 @@
 #include "dqmc_host.hpp"
 #include "results_h5.hpp"
 
+#include <sys/stat.h>
 #include <unistd.h>
 
 #include <chrono>
@@ -54,14 +55,19 @@ dqmc_comm* rccl_world(const World& w, int device) {
     char id[DQMC_UNIQUE_ID_BYTES];
     if (w.rank == 0) {
         dqmc_detail::check(dqmc_comm_unique_id(id));
+        std::remove(path.c_str());                                  // a stale leftover of an earlier run
         const std::string tmp = path + ".tmp";
         { std::ofstream f(tmp, std::ios::binary); f.write(id, sizeof(id)); }
         if (std::rename(tmp.c_str(), path.c_str()) != 0) throw std::runtime_error("cannot publish the RCCL id at " + path);
     } else {
+        // a file left behind by a crashed run of the same launcher pid must not be taken for this run's: only a file written after
+        // this process started (minus a margin for launcher skew) counts
+        const time_t t_start = time(nullptr) - 120;
         bool ok = false;
         for (int tries = 0; tries < 6000 && !ok; ++tries) {
+            struct stat stt;
             std::ifstream f(path, std::ios::binary);
-            if (f.is_open() && f.read(id, sizeof(id)) && f.gcount() == (std::streamsize)sizeof(id)) ok = true;
+            if (stat(path.c_str(), &stt) == 0 && stt.st_mtime >= t_start && f.is_open() && f.read(id, sizeof(id)) && f.gcount() == (std::streamsize)sizeof(id)) ok = true;
             else std::this_thread::sleep_for(std::chrono::milliseconds(10));
         }
         if (!ok) throw std::runtime_error("timed out waiting for the RCCL id at " + path);

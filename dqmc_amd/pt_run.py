@@ -21,19 +21,38 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def run_pt(d, lib, betas, L, U, nt, n_stab, therm, sweeps, sweep_steps, seed=1234, log=print):
-    """Returns (sweeps/s of this rank, exchange_attempt, exchange_accepted of rank 0's pairs)."""
+def gloo_sendrecv(dist):
+    """An MPI_Sendrecv-shaped callback over torch.distributed point-to-point (any backend that does CPU tensors, i.e. gloo): the
+    callback transport of dqmc_comm_create_callbacks between real processes -- ranks that share a GPU (RCCL refuses two ranks on
+    one device), or a host without RCCL."""
+    import torch
+
+    def sendrecv(send: bytes, partner: int, tag: int) -> bytes:
+        t_send = torch.frombuffer(bytearray(send), dtype=torch.uint8); t_recv = torch.empty_like(t_send)
+        for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, t_send, partner), dist.P2POp(dist.irecv, t_recv, partner)]):
+            w.wait()
+        return t_recv.numpy().tobytes()
+    return sendrecv
+
+
+def run_pt(d, lib, betas, L, U, nt, n_stab, therm, sweeps, sweep_steps, seed=1234, log=print, transport="rccl", device=None):
+    """Returns (sweeps/s of the slowest rank, exchange_attempt, exchange_accepted of rank 0's pairs).  transport: "rccl" (one GPU per
+    rank, fields HBM to HBM) or "callbacks" (dqmc_comm_create_callbacks over torch.distributed point-to-point)."""
     import torch.distributed as dist
     from dqmc_amd import HubbardModel
     if len(betas) != d.world:
         raise SystemExit(f"ERROR: The number of betas ({len(betas)}) must match the number of processes ({d.world}).")
     if d.world % 2 != 0:
         raise SystemExit(f"ERROR: currently number of processor ( nprocs = {d.world}) need to be even for replica exchange")
-    ids = [lib.comm_unique_id() if d.rank == 0 else None]
-    dist.broadcast_object_list(ids, src=0)
-    comm = lib.comm_rccl(ids[0], d.world, d.rank, d.local_rank)
+    dev = d.local_rank if device is None else device
+    if transport == "rccl":
+        ids = [lib.comm_unique_id() if d.rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        comm = lib.comm_rccl(ids[0], d.world, d.rank, dev)
+    else:
+        comm = lib.comm_callbacks(d.world, d.rank, gloo_sendrecv(dist))
     model = HubbardModel(L1=L, L2=L, U=U, beta=float(betas[d.rank]), nt=nt, n_stab=n_stab)
-    eng = model.engine(lib, device=d.local_rank)
+    eng = model.engine(lib, device=dev)
     eng.set_fields(model.random_fields(seed + d.rank)); eng.init()
     rng = np.random.default_rng(seed + 1000 + d.rank)
 
@@ -60,8 +79,11 @@ def run_pt(d, lib, betas, L, U, nt, n_stab, therm, sweeps, sweep_steps, seed=123
     dt = time.perf_counter() - t0
     st = eng.stats()
     sums = comm.allreduce_sum([dt, st.n_accepted / max(1, st.n_proposed)])        # the two MPI_Reduce(SUM), source/main.cpp:186-187
+    slow = [None] * d.world
+    dist.all_gather_object(slow, dt)
+    dt = max(slow)                                                                 # the job is as fast as its slowest rank
     if d.rank == 0:
-        log(f"PT: {d.world} replicas over {comm.transport}, {sweeps} sweeps in {dt:.2f} s = {d.world * sweeps / dt:.2f} sweeps/s total; "
+        log(f"PT: {d.world} replicas over {comm.transport}, {sweeps} sweeps in {dt:.2f} s (mean over ranks {sums[0] / d.world:.2f} s) = {d.world * sweeps / dt:.2f} sweeps/s total; "
             f"acceptance {sums[1] / d.world:.4f}; exchange rate {accepted / max(1, attempt):.4f} ({accepted}/{attempt}), "
             f"{1e3 * t_ex / max(1, attempt):.1f} ms per round; max wrap err {st.max_err:.3e}")
     comm.close(); eng.close()

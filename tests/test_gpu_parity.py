@@ -261,9 +261,10 @@ def test_cfg3_one_block_then_properties(hip, orc):
 
 
 def test_cfg5_size_streaming_kernels(hip, orc):
-    """cfg 5 (24x24, beta=10, Ltau=400, n_stab=10): N = 576 takes the streaming QRCP (9 rows per lane),
-    the guarded GEMM tiles and the 576-thread update kernel.  The oracle (LAPACK back end when present,
-    for speed) checks G(0,0) / log det from scratch and one stabilisation block of the forward sweep."""
+    """cfg 5 (24x24, beta=10, Ltau=400, n_stab=10): N = 576 takes the cooperative multi-workgroup QRCP (qr_coop.hip), the
+    LDS-staged 32x32-tile GEMM, the Gauss-Jordan solve with the 10-wave panel and the persistent sub-matrix slice kernel
+    (update_sm.hip).  The oracle (LAPACK back end when present, for speed) checks G(0,0) / log det from scratch and one
+    stabilisation block of the forward sweep."""
     m = HubbardModel(**CONFIGS["cfg5"]); f = m.random_fields(55)
     e = m.engine(hip); e.set_fields(f); e.init()
     fast = orc.set_backend("lapack")
@@ -424,7 +425,7 @@ def test_alternative_kernel_paths_in_subprocess(hip):
         assert out.returncode == 0, (env_extra, out.stderr[-2000:])
         return json.loads(out.stdout.strip().splitlines()[-1])
     for env in ({}, {"DQMC_WALK_SUBMATRIX": "1"}, {"DQMC_SLICE_MULTIKERNEL": "1"}, {"DQMC_SLICE_PAIRS": "1"}, {"DQMC_SLICE_SOLO": "1"}, {"DQMC_LU_CLASSIC": "1"},
-                {"DQMC_GJ_PANEL_1W": "1"}, {"DQMC_QR_STREAMING": "1"}, {"DQMC_FORMQ_CLASSIC": "1"}, {"DQMC_INIT_SEQUENTIAL": "1"}, {"DQMC_TRI_CLASSIC": "1"}):
+                {"DQMC_QR_STREAMING": "1"}, {"DQMC_INIT_SEQUENTIAL": "1"}):
         got = run(env)
         print(env, {k: (v["d0"], v["dA"]) if "d0" in v else v["dA"] for k, v in got.items()})
         for name in ("cfg2_therm", "cfg3_therm"):
@@ -451,7 +452,7 @@ def test_alternative_kernel_paths_above_256_in_subprocess(hip):
             "    e = m.engine(dqmc_amd.lib()); e.set_fields(f); e.init(); G0 = e.get_G(); e.sweep_0_to_beta(*st)\n"
             "    np.savez(sys.argv[1] + str(L) + '.npz', G0=G0, G1=e.get_G(), f=e.get_fields(), acc=e.stats().n_accepted)\n") % root
     ref = {L: body(L) for L in (24, 20)}
-    for env in ({"DQMC_GEMM_NO_STAGE32": "1"}, {"DQMC_GJ_MAX_N": "256"}, {"DQMC_TRI_CLASSIC": "1"}, {"DQMC_QR_STREAMING": "1"}, {"DQMC_SLICE_MULTIKERNEL": "1"}):
+    for env in ({"DQMC_GEMM_NO_STAGE32": "1"}, {"DQMC_GJ_MAX_N": "256"}, {"DQMC_QR_STREAMING": "1"}, {"DQMC_SLICE_MULTIKERNEL": "1"}):
         with tempfile.TemporaryDirectory() as td:
             e2 = dict(os.environ); e2.update(env)
             out = subprocess.run([sys.executable, "-c", code, os.path.join(td, "r")], env=e2, capture_output=True, text=True, timeout=600)

@@ -157,6 +157,53 @@ def test_exchange_round_through_the_c_abi(hip, orc):
         e.close()
 
 
+def test_exchange_rounds_between_two_processes(hip, orc, tmp_path):
+    """The reference's ranks are PROCESSES (source/main.cpp:20-37): two child processes, one HIP engine each on device 0, the
+    library's communicator over the callback transport with gloo point-to-point as the MPI_Sendrecv (tests/pt_two_proc.py).  Round 1
+    is a forced accept, round 2 a forced reject; partners, decider, the four actions, deltaS, the exchanged fields and G are
+    compared with oracle engines here.  The children then run dqmc_amd/pt_run.py's cfg-4 loop over the same transport."""
+    import socket, sys
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+    here = os.path.dirname(os.path.abspath(__file__))
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(here, "pt_two_proc.py"), str(tmp_path)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, (r, outs[r][0][-1500:], outs[r][1][-3000:])
+    z = [np.load(tmp_path / f"rank{r}.npz") for r in range(2)]
+    betas = [2.0, 1.6]
+    models = [HubbardModel(L1=4, L2=4, U=4.0, beta=b, nt=20, n_stab=10) for b in betas]
+    f0 = [models[r].random_fields(100 + r) for r in range(2)]
+    ref = [models[r].engine(orc) for r in range(2)]
+    S, Sp = [], []
+    for r in range(2):
+        ref[r].set_fields(f0[r]); ref[r].init(); S.append(ref[r].global_action())
+    for r in range(2):
+        ref[r].set_fields(f0[1 - r]); ref[r].init(); Sp.append(ref[r].global_action())       # ref[r] now holds the partner's fields
+    dS = (Sp[0] + Sp[1]) - (S[0] + S[1])
+    for r in range(2):
+        partner, decider, accepted, s_, sp_, s_part, sp_part, ds_ = z[r]["res1"]
+        assert (int(partner), int(decider), int(accepted)) == (1 - r, 1 if r == 0 else 0, 1)
+        assert abs(s_ - S[r]) < 1e-9 * abs(S[r]) and abs(sp_ - Sp[r]) < 1e-9 * abs(Sp[r]) and abs(s_part - S[1 - r]) < 1e-9 * abs(S[1 - r])
+        assert abs(sp_part - Sp[1 - r]) < 1e-9 * abs(Sp[1 - r]) and abs(ds_ - dS) < 1e-7
+        assert np.array_equal(z[r]["fields1"], f0[1 - r])                                    # accepted: the partner's fields, across the process boundary
+        assert np.abs(z[r]["G1"] - ref[r].get_G()).max() < TOL
+        assert abs(float(z[r]["logdet1"]) - ref[r].get_logdet()) < 1e-9 * max(1.0, abs(ref[r].get_logdet()))
+        partner, decider, accepted, s_, sp_, *_ = z[r]["res2"]
+        assert (int(partner), int(accepted)) == (1 - r, 0)                                   # attempt 2 of a world of two pairs the same ranks
+        assert abs(s_ - Sp[r]) < 1e-9 * abs(Sp[r]) and abs(sp_ - S[r]) < 1e-9 * abs(S[r])    # own action is now the swapped one, the trial the original
+        assert np.array_equal(z[r]["fields2"], f0[1 - r])                                    # rejected: restored = still the swapped configuration
+        assert np.abs(z[r]["G2"] - ref[r].get_G()).max() < TOL
+        rate, attempts, acc = z[r]["pt"]
+        assert rate > 0 and int(attempts) == 3 and 0 <= int(acc) <= 3                        # 6 sweeps, exchange every 2
+    assert "2 replicas over callbacks" in str(z[0]["pt_log"])
+    for e in ref:
+        e.close()
+
+
 def test_driver_parallel_tempering_in_process(hip, tmp_path):
     """dqmc_driver with [ParallelTempering] enabled = true and no launcher: one thread per beta on the visible GPU,
     swaps through update::InProcessHub (source/main.cpp:39-67,146-153,203-208)."""
