@@ -11,9 +11,10 @@
 // reference's; only the rounding order of the rank-1 sums differs.
 //
 // Kernels (blockIdx.y = chain, thread j <-> site j):
-//   slice_kernel        n <= 256, few chains: the whole slice in ONE launch -- workgroup 0 walks (walk_window), the other
+//   slice_kernel        n <= 256, few chains: the whole slice in ONE launch -- workgroup 0 walks (walk_window6), the other
 //                       (n/32)^2 workgroups each own a tile of G and of its transposed copy GT and flush every window;
-//                       hand-offs through one tagged word and one arrival counter, see the comment at the kernel.
+//                       hand-offs through tagged words (SliceSync, common.h), see the comment at the kernel.
+//   slice_solo_kernel   many chains: one workgroup per chain walks AND flushes.
 //   scan_kernel<256> +  the same walk / flush code as separate launches, ceil(N/KD) pairs per slice (pairs past the end of
 //   flush_kernel<true>  the walk find pos == N / k == 0 and exit); used when the single-launch grid would not be co-resident.
 //   scan_kernel<1024> + n > 256: the pending pairs live in LDS (scan_group), G rows are read directly (no GT).
@@ -184,226 +185,25 @@ __device__ __forceinline__ bool scan_group(const double (&pc)[SCAN_PF], const do
 }
 
 
-// ---- walk v3 (n <= 256: one wave per SIMD, 512 VGPRs per lane) ------------------------------------------------------
-// What the stamps of the LDS variant above showed, per accepted flip at the average k = 16 (cycles):
-//   ~1250 pending-pair loop: LDS-bandwidth bound (each lane reads its own pairs AND the pivot's pairs; a broadcast
-//         read still occupies the pipe for 64 lanes x 16 B: 4 waves x 2k reads x 8 clk),
-//   ~ 550 two barriers, each a vmcnt(0) because __syncthreads() is a release fence and the panel rows were stored to
-//         HBM as they were produced -- and stores in flight also forbid partial vmcnt waits on the prefetch loads,
-//   ~ 200 per proposal for the serial decision chain (site -> diag -> ratio), rejected ones included,
-//   and the row prefetch G[site, :] touches one 128-B line per lane (the whole of G every 16 proposals).
-// This variant therefore
-//   * keeps a lane's own pending pairs {U_m[j], W_m[j]} in REGISTERS (vector types, so that the slot written per
-//     accepted flip is a wave-uniform s_set_gpr_idx move, not a scratch array),
-//   * fetches the pivot's pairs {U_m[i], W_m[i]} with two compact LDS reads per wave (lane r of every 16-lane row
-//     holds pairs r and 16 + r) and feeds them to the FMAs straight from the DPP network
-//     (v_fmac_f64_dpp row_newbcast:r -- CDNA's only 64-bit DPP mode), no readlane / SGPR round trip,
-//   * evaluates the Metropolis decision for the next 64 proposals at once (lane t <-> proposal pos + t) and jumps
-//     to the first accepted one: decisions after it are discarded because the diagonal changes, rejected ones before
-//     it are exact, so the cost per accepted flip no longer depends on how many rejections lie in between,
-//   * issues NO global store inside the walk: panel rows, fields and exp(V) entries are written when the window
-//     closes (from registers / a 32-entry LDS list); barriers order LDS only,
-//   * reads the row G[site, :] from a transposed copy GT that the flush keeps in step with G (coalesced),
-//   * double-buffers the diagonal in LDS (one barrier per accepted flip instead of two).
-typedef double d16v __attribute__((ext_vector_type(16)));
-
-// Compiler note: the register-resident vectors must be LOCAL variables, handed to helpers by value and returned by
-// value.  Taken by reference (or as members of a struct passed by reference) their dynamically indexed element
-// accesses become variable GEPs into an alloca that SROA cannot promote, and the whole set lands in scratch.
-
-// G[j, site] (pc) and G[site, j] (pr, read from the transposed copy) of the 8 proposals of group g.  Plain arrays with
-// compile-time indices only: they may live in AGPRs (the 256 architectural VGPRs are taken by the pending pairs).
-template <bool COH>
-__device__ __forceinline__ void walk_load_group(double (&pc)[8], double (&pr)[8], const double* __restrict__ G, const double* __restrict__ GT,
-                                                const ScanShared& sh, int g, int n, int j, bool live) {
-    const int jj = live ? j : n - 1;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const int i = sh.site[min(g * 8 + q, n - 1)];             // clamped: loads stay unconditional
-        // 32-bit byte offset from a wave-uniform base: the loads take the (SGPR base + VGPR offset) form, one VALU
-        // instruction per address pair instead of two 64-bit multiply-adds
-        const unsigned off8 = (unsigned)(jj + n * i) * 8u;
-        const double* gp = reinterpret_cast<const double*>(reinterpret_cast<const char*>(G) + off8);
-        const double* tp = reinterpret_cast<const double*>(reinterpret_cast<const char*>(GT) + off8);
-        if (COH) { pc[q] = ld_coh(gp); pr[q] = ld_coh(tp); }
-        else { pc[q] = *gp; pr[q] = *tp; }
-    }
-}
-__device__ __forceinline__ d16v vec_set(d16v v, int q, double x) { v[q] = x; return v; }
-__device__ __forceinline__ double vec_get16(d16v v, int q) { return v[q]; }
-
-#define DQ_PICK8(PC, PR)                                                                                            \
-    switch (first) {                                                                                                \
-        case 0: uj = PC[0]; wj = PR[0]; break; case 1: uj = PC[1]; wj = PR[1]; break;                               \
-        case 2: uj = PC[2]; wj = PR[2]; break; case 3: uj = PC[3]; wj = PR[3]; break;                               \
-        case 4: uj = PC[4]; wj = PR[4]; break; case 5: uj = PC[5]; wj = PR[5]; break;                               \
-        case 6: uj = PC[6]; wj = PR[6]; break; default: uj = PC[7]; wj = PR[7]; break;                              \
-    }
-
-// four pending pairs m = MB .. MB+3 of one 16-slot half: acc_u += own_u[m] * W_m[i], acc_w += U_m[i] * own_w[m], the pivot
-// values taken from lane m of each 16-lane row.  One asm block: the compiler's hazard recogniser does not look inside
-// inline asm, so the block opens with the wait states a DPP read of a just-written VGPR needs.
-#define DQ_FMAC4(R0, R1, R2, R3, ua, wa, ub, wb, pvx, pvy, OU, OW, MB)                                                                    \
-    asm("s_nop 1\n\t"                                                                                                                     \
-        "v_fmac_f64_dpp %0, %5, %6 row_newbcast:" #R0 " row_mask:0xf bank_mask:0xf\n\t"                                                   \
-        "v_fmac_f64_dpp %1, %4, %7 row_newbcast:" #R0 " row_mask:0xf bank_mask:0xf\n\t"                                                   \
-        "v_fmac_f64_dpp %2, %5, %8 row_newbcast:" #R1 " row_mask:0xf bank_mask:0xf\n\t"                                                   \
-        "v_fmac_f64_dpp %3, %4, %9 row_newbcast:" #R1 " row_mask:0xf bank_mask:0xf\n\t"                                                   \
-        "v_fmac_f64_dpp %0, %5, %10 row_newbcast:" #R2 " row_mask:0xf bank_mask:0xf\n\t"                                                  \
-        "v_fmac_f64_dpp %1, %4, %11 row_newbcast:" #R2 " row_mask:0xf bank_mask:0xf\n\t"                                                  \
-        "v_fmac_f64_dpp %2, %5, %12 row_newbcast:" #R3 " row_mask:0xf bank_mask:0xf\n\t"                                                  \
-        "v_fmac_f64_dpp %3, %4, %13 row_newbcast:" #R3 " row_mask:0xf bank_mask:0xf"                                                      \
-        : "+v"(ua), "+v"(wa), "+v"(ub), "+v"(wb)                                                                                          \
-        : "v"(pvx), "v"(pvy), "v"(OU[MB]), "v"(OW[MB]), "v"(OU[MB + 1]), "v"(OW[MB + 1]), "v"(OU[MB + 2]), "v"(OW[MB + 2]), "v"(OU[MB + 3]),    \
-          "v"(OW[MB + 3]))
-
-// Walks one window: from proposal `pos` until KD flips are pending or the slice is over, then writes the window's
-// panel rows (the flush's operands) and field changes to memory.  Returns the number of flips.
-//   dg: the lane's own diagonal entry (sh.diag holds the diagonal on entry)
-// Proposals are handled in groups of 8 with three register sets used round-robin (the group loop is unrolled by 3 so
-// that every set is addressed statically): while group g is walked, the G column / row elements of groups g + 1 and
-// g + 2 are in flight, and nothing but those loads is outstanding, so the wait before a group is a partial vmcnt.
-template <bool COH, bool PANELS = true>     // PANELS: write the window's U / W rows to memory for flush workgroups / kernels (the solo kernel flushes from LDS)
-__device__ __forceinline__ int walk_window(const ScanShared& sh, int& pos, double& dg, int n, int kd, int j, bool live, const double* __restrict__ G,
-                                           const double* __restrict__ GT, const UpdateDesc& d, long slice_off, int chain, int8_t* fields_g,
-                                           double* __restrict__ Up, double* __restrict__ Wp PROF_ARG) {
-    const int lane = threadIdx.x & 63, r16 = lane & 15, q8 = lane & 7;
-    d16v ou0, ou1, ow0, ow1;                                      // own pending pairs: U_m[j], W_m[j] for m < 16 | m >= 16
-    double pc0[8], pr0[8], pc1[8], pr1[8], pc2[8], pr2[8];        // prefetched G column / row elements of group (g % 3)
-#pragma unroll
-    for (int m = 0; m < 16; ++m) { ou0[m] = 0.0; ou1[m] = 0.0; ow0[m] = 0.0; ow1[m] = 0.0; }
-    int par = 0, k = 0;
-    int g = pos >> 3;
-    bool done = false;
-#ifdef DQ_SCAN_STAMPS
-    unsigned long long tw0; STAMP(tw0) bool first_acc = true;
-#endif
-    // sets of groups g and g + 1 (the group macro below requests g + 2 when it starts on g)
-    switch (g % 3) {
-        case 0: walk_load_group<COH>(pc0, pr0, G, GT, sh, g, n, j, live); walk_load_group<COH>(pc1, pr1, G, GT, sh, g + 1, n, j, live); break;
-        case 1: walk_load_group<COH>(pc1, pr1, G, GT, sh, g, n, j, live); walk_load_group<COH>(pc2, pr2, G, GT, sh, g + 1, n, j, live); break;
-        default: walk_load_group<COH>(pc2, pr2, G, GT, sh, g, n, j, live); walk_load_group<COH>(pc0, pr0, G, GT, sh, g + 1, n, j, live); break;
-    }
-#ifdef DQ_SCAN_STAMPS
-#define DQ_ST(...) __VA_ARGS__
-#else
-#define DQ_ST(...)
-#endif
-#define DQ_GROUP(PCS, PRS, PCT, PRT)                                                                                                     \
-    {                                                                                                                                    \
-        walk_load_group<COH>(PCT, PRT, G, GT, sh, g + 2, n, j, live);                                                                    \
-        const int gbase = g * 8;                                                                                                         \
-        /* what lane q needs to decide proposal gbase + q is read once per group; only the diagonal changes between passes */           \
-        const int p_l = gbase + q8, pc_l = min(p_l, n - 1);                                                                              \
-        const int i_l = sh.site[pc_l];                                                                                                   \
-        const double dl_l = sh.dlt[pc_l], rb_l = sh.rbv[pc_l], ur_l = sh.ur[pc_l];                                                       \
-        for (;;) {                                                                                                                       \
-            DQ_ST(unsigned long long t0, t1, t2, t3; STAMP(t0))                                                                          \
-            /* decisions for the (remaining) proposals of the group under the current diagonal: lane q <-> proposal gbase + q */         \
-            const double* dcur = par ? sh.diag2 : sh.diag;                                                                               \
-            const double r_l = 1.0 + (1.0 - dcur[i_l]) * dl_l;                 /* det ratio per flavour (source/model.cpp:95) */          \
-            const double R_l = rb_l * (r_l * r_l);                              /* :121 */                                               \
-            const double pref_l = dl_l / r_l;                                   /* source/model.cpp:132, for every candidate: the division overlaps the decision */ \
-            /* bernoulli(min(1,|R|)): u < p (source/update.cpp:24, include/utility.h:34-37) */                                           \
-            const bool acc_l = p_l >= pos && p_l < n && ur_l < fmin(1.0, fabs(R_l));                                                     \
-            const unsigned bal = (unsigned)__ballot(acc_l) & 0xffu;                                                                      \
-            if (bal == 0u) { pos = min(gbase + 8, n); DQ_ST(STAMP(t1) prof.t_noacc += t1 - t0; prof.n_noacc++;) break; }   /* the rest of the group is rejected */ \
-            const int first = __ffs((int)bal) - 1;                                                                                       \
-            const int p = gbase + first;                                                                                                 \
-            pos = p + 1;                                                                                                                 \
-            const int i = __builtin_amdgcn_readlane(i_l, first);                                                                         \
-            const double pref = readlane_f64(pref_l, first);                                                                             \
-            /* pivot pairs: lane r16 of every row holds {U_m[i], W_m[i]} for m = r16 (pa) and m = 16 + r16 (pb) */                        \
-            const int kc = max(k - 1, 0);                                                                                                \
-            double2 pa = sh.UW[min(r16, kc) * n + i], pb = sh.UW[min(16 + r16, kc) * n + i];                                             \
-            if (r16 >= k) { pa.x = 0.0; pa.y = 0.0; }                                                                                    \
-            if (16 + r16 >= k) { pb.x = 0.0; pb.y = 0.0; }                                                                               \
-            double uj, wj;                                                                                                               \
-            DQ_PICK8(PCS, PRS)                                                                                                           \
-            DQ_ST(STAMP(t1) if (first_acc) { first_acc = false; asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); unsigned long long tf; STAMP(tf) prof.t_first += tf - tw0; })  \
-            /* G_eff[:, i], G_eff[i, :]: 2k FMAs per lane, pivot operand broadcast by DPP */                                             \
-            double u1 = 0.0, w1 = 0.0;                                                                                                   \
-            if (k > 0) {                                        /* eight pairs per scalar branch (slots k.. of the last octet hold zeros in pa / pb) */ \
-                DQ_FMAC4(0, 1, 2, 3, uj, wj, u1, w1, pa.x, pa.y, ou0, ow0, 0); DQ_FMAC4(4, 5, 6, 7, uj, wj, u1, w1, pa.x, pa.y, ou0, ow0, 4);     \
-                if (k > 8) { DQ_FMAC4(8, 9, 10, 11, uj, wj, u1, w1, pa.x, pa.y, ou0, ow0, 8); DQ_FMAC4(12, 13, 14, 15, uj, wj, u1, w1, pa.x, pa.y, ou0, ow0, 12); }   \
-                if (k > 16) { DQ_FMAC4(0, 1, 2, 3, uj, wj, u1, w1, pb.x, pb.y, ou1, ow1, 0); DQ_FMAC4(4, 5, 6, 7, uj, wj, u1, w1, pb.x, pb.y, ou1, ow1, 4); }         \
-                if (k > 24) { DQ_FMAC4(8, 9, 10, 11, uj, wj, u1, w1, pb.x, pb.y, ou1, ow1, 8); DQ_FMAC4(12, 13, 14, 15, uj, wj, u1, w1, pb.x, pb.y, ou1, ow1, 12); } \
-            }                                                                                                                            \
-            uj += u1; wj += w1;                                                                                                          \
-            if (j == i) wj -= 1.0;                                              /* V(i) -= 1 (source/model.cpp:135) */                   \
-            const double pu = pref * uj;                                                                                                 \
-            DQ_ST(STAMP(t2))                                                                                                             \
-            dg += pu * wj;                                                                                                               \
-            if (live) {                                                                                                                  \
-                sh.UW[k * n + j] = make_double2(pu, wj);                        /* slot k: read by nobody before the barrier below */    \
-                (par ? sh.diag : sh.diag2)[j] = dg;                             /* the buffer no wave is reading */                      \
-            }                                                                                                                            \
-            if (j == 0) sh.acc_site[k] = p;                                     /* fields are written at window end */                   \
-            const int ks = k & 15;                                                                                                       \
-            { /* branch-free slot write: an if / else around the two halves makes every vector a phi and the allocator copies    */       \
-              /* 32-register tuples (VGPR <-> AGPR) on the loop back-edge -- ~100 moves per accepted flip                         */       \
-                const bool lo = k < 16;                                                                                                  \
-                ou0 = vec_set(ou0, ks, lo ? pu : vec_get16(ou0, ks)); ow0 = vec_set(ow0, ks, lo ? wj : vec_get16(ow0, ks));              \
-                ou1 = vec_set(ou1, ks, lo ? vec_get16(ou1, ks) : pu); ow1 = vec_set(ow1, ks, lo ? vec_get16(ow1, ks) : wj); }            \
-            ++k; par ^= 1;                                                                                                               \
-            lds_barrier();                                                                                                               \
-            DQ_ST(STAMP(t3) prof.t_wait += t1 - t0; prof.t_kloop += t2 - t1; prof.t_tail += t3 - t2; prof.n_acc++;)                      \
-            if (k >= kd) { done = true; break; }                                                                                         \
-        }                                                                                                                                \
-        if (pos >= n) done = true;                                                                                                       \
-        ++g;                                                                                                                             \
-    }
-    while (!done) {
-        switch (g % 3) {
-            case 0: DQ_GROUP(pc0, pr0, pc2, pr2) if (done) break; [[fallthrough]];
-            case 1: DQ_GROUP(pc1, pr1, pc0, pr0) if (done) break; [[fallthrough]];
-            default: DQ_GROUP(pc2, pr2, pc1, pr1) break;
-        }
-    }
-#undef DQ_GROUP
-#undef DQ_ST
-#ifdef DQ_SCAN_STAMPS
-    unsigned long long td0; STAMP(td0)
-#endif
-    // ---- window end: the flush's operands and the accepted field changes leave the workgroup (coalesced, from registers) ----
-    if (PANELS && live) {
-#define DQ_DUMP(OU, OW, M, BASE)                                                                       \
-        if (COH) { st_coh(Up + (BASE + M) * n + j, OU[M]); st_coh(Wp + (BASE + M) * n + j, OW[M]); }   \
-        else { Up[(BASE + M) * n + j] = OU[M]; Wp[(BASE + M) * n + j] = OW[M]; }
-#pragma unroll
-        for (int m = 0; m < 16; ++m) { if (m >= k) break; DQ_DUMP(ou0, ow0, m, 0) }
-#pragma unroll
-        for (int m = 0; m < 16; ++m) { if (16 + m >= k) break; DQ_DUMP(ou1, ow1, m, 16) }
-#undef DQ_DUMP
-    }
-    if (j < k) {
-        const int p = sh.acc_site[j];
-        const int i = sh.site[p], new_f = sh.newf[p];
-        fields_g[i] = (int8_t)new_f;                                        // field.set_single_field (source/update.cpp:28)
-        d.expv[(long)chain * d.v_stride + slice_off + i] = sh.tl[24 + new_f];
-        d.invexpv[(long)chain * d.v_stride + slice_off + i] = sh.tl[28 + new_f];
-    }
-#ifdef DQ_SCAN_STAMPS
-    { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); unsigned long long td1; STAMP(td1) prof.t_dump += td1 - td0; }
-#endif
-    return k;
-}
-static_assert(UPDATE_KD == 32, "walk v3 keeps 2 x 16 pending pairs per lane in registers");
-
-// ---- walk v6: v3's structure, pending pairs and prefetch sets in a hand-managed register file ------------------------------------
-// Stamps and the ISA of v3 and of an intermediate version with compiler-managed scalars (round 3): of ~2 400 clk per
-// accepted flip ~300 went into writing the new pair into a dynamically indexed register slot, ~120 into FMAs on padded octets and
-// their masking selects, ~150 into an IEEE division that the compiler had sunk behind the decision; with 64 named scalars and a
-// dispatch on K instead, the allocator's reconciliation moves at the joins cost ~1 000 clk per flip.  Here
-//   * the pairs and the three prefetch sets live in registers the allocator never sees (walk_bodies.inc, generated: literal
-//     register names, kernels compiled with amdgpu_num_vgpr(64));
-//   * the accepted-flip body exists once per pending-pair count K = 0..31: exactly 2K DPP FMAs, the new pair is two moves;
-//   * the pivot's two prefetched G elements are picked lazily, on acceptance only, by an if / else tree over (set, proposal)
-//     behind a counted s_waitcnt vmcnt(32) (the two younger groups' 32 loads may still be in flight);
-//   * pref = delta / r (source/model.cpp:132) is formed BEFORE the ballot from v_rcp_f64 + two Newton steps + one residual
-//     correction, interleaved with the decision chain instead of behind it.
-// Everything else -- decisions for 8 proposals at once, prefetch three groups deep, double-buffered diagonal, one LDS barrier
-// per accepted flip, no global store inside the walk -- is v3's.
+#define DQ_WALK_REGS __attribute__((amdgpu_num_vgpr(64)))     // allocator confined to v0..v127: v128..v255 and a0..a95 are the walk's (walk_bodies.inc)
+// ---- the Metropolis walk of one window (n <= 256: one wave per SIMD) ------------------------------------------------------------
+// Per accepted flip the walk needs u = G_eff[:, i] and w = G_eff[i, :] - e_i of the effective Green's function
+// G_eff = G + sum_m U_m W_m^T (delayed updates): one pass over the k <= 32 pending pairs.  How it is organised, and why (round-3
+// stamps and ISA):
+//   * decisions for 8 proposals at once (lane q <-> proposal 8 g + q), ballot + first-set jump over the rejections; decisions after
+//     the first accepted one are discarded because the diagonal changes, rejected ones before it are exact;
+//   * a lane's own pairs {U_m[j], W_m[j]} and the prefetched G column / row elements of three groups of 8 proposals live in
+//     registers the allocator never sees (walk_bodies.inc, generated: literal register names, kernels compiled with
+//     amdgpu_num_vgpr(64)).  Left to the allocator they were the walk's main cost: as vectors with a dynamic slot index, 24
+//     s_set_gpr_idx mode switches + 16 moves + 8 selects per flip; as named scalars behind a dispatch on k, ~70 reconciliation moves
+//     at the joins and one prefetch set loaded into temporaries behind s_waitcnt vmcnt(0);
+//   * the pass over the pairs is ONE chain of 2 x 32 v_fmac_f64_dpp (pivot entries {U_m[i], W_m[i]}: two compact LDS reads, lane r
+//     of every 16-lane row holds pairs r and 16 + r, broadcast by row_newbcast), entered at pair k - 1 by a computed jump: exactly
+//     2k FMAs run, nothing is masked, the code exists once;
+//   * the pivot's two prefetched G elements are picked lazily, on acceptance only, behind a counted s_waitcnt vmcnt(32) (the two
+//     younger groups' 32 loads may still be in flight); the row G[site, :] is read from the transposed copy GT (coalesced);
+//   * NO global store inside the walk: panel rows, fields and exp(V) entries are written when the window closes; barriers order
+//     LDS only; the diagonal is double-buffered in LDS (one barrier per accepted flip).
 #include "walk_bodies.inc"
 #pragma clang diagnostic ignored "-Winline-asm"
 
@@ -433,8 +233,12 @@ __device__ __forceinline__ int walk_window6(const ScanShared& sh, int& pos, doub
     int par = 0, k = 0;
     int g = pos >> 3;
     bool done = false;
-    // no vector-memory operation of this workgroup may be in flight when the counted waits below start counting
+    // no vector-memory operation of this workgroup may be in flight when the counted waits below start counting.  Twice on purpose:
+    // the asm is the real wait; the builtin is the one the compiler's waitcnt pass understands -- without it a load of the caller's
+    // hand-off loop (a poll whose result it considers pending around the window loop) made it put s_waitcnt vmcnt(0) in front of the
+    // pair pass of EVERY accepted flip, i.e. a wait for the 32 prefetch loads just issued (seen in the ISA; +100 ns per flip)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0x0F70);                                        // vmcnt(0), expcnt / lgkmcnt untouched
     walk6_load_group<COH>(G, GT, sh, g, g % 3, n, j, live);
     walk6_load_group<COH>(G, GT, sh, g + 1, (g + 1) % 3, n, j, live);
 #ifdef DQ_SCAN_STAMPS
@@ -457,14 +261,8 @@ __device__ __forceinline__ int walk_window6(const ScanShared& sh, int& pos, doub
             // decisions for the (remaining) proposals of the group under the current diagonal: lane q <-> proposal gbase + q
             const double* dcur = par ? sh.diag2 : sh.diag;
             const double r_l = 1.0 + (1.0 - dcur[i_l]) * dl_l;                  // det ratio per flavour (source/model.cpp:95)
-            // pref = delta / r (source/model.cpp:132) for every candidate, ahead of the decision
-            double y_ = __builtin_amdgcn_rcp(r_l);
-            double e_ = __builtin_fma(-r_l, y_, 1.0); y_ = __builtin_fma(y_, e_, y_);
-            e_ = __builtin_fma(-r_l, y_, 1.0); y_ = __builtin_fma(y_, e_, y_);
-            double pref_l = dl_l * y_;
-            pref_l = __builtin_fma(__builtin_fma(-r_l, pref_l, dl_l), y_, pref_l);
+            const double pref_l = dl_l / r_l;                                    // source/model.cpp:132 (IEEE division; a v_rcp_f64 + Newton form hoisted in front of the ballot measured 0.6 % slower)
             const double R_l = rb_l * (r_l * r_l);                               // :121
-            asm volatile("" : "+v"(pref_l));                                     // keeps the quotient in front of the branch
             // bernoulli(min(1,|R|)): u < p (source/update.cpp:24, include/utility.h:34-37)
             const bool acc_l = p_l >= pos && p_l < n && ur_l < fmin(1.0, fabs(R_l));
             const unsigned bal = (unsigned)__ballot(acc_l) & 0xffu;
@@ -480,9 +278,21 @@ __device__ __forceinline__ int walk_window6(const ScanShared& sh, int& pos, doub
             if (gs == 0) { DQ_W6_PICK_0 } else if (gs == 1) { DQ_W6_PICK_1 } else { DQ_W6_PICK_2 }
             double uj = __hiloint2double(uhi, ulo), wj = __hiloint2double(whi, wlo);
             DQ_ST(STAMP(t1))
-            int jv = j, r16v = r16;
-            asm volatile("" : "+v"(jv), "+v"(r16v));                             // see walk_bodies.inc: keeps the bodies' address arithmetic inside them
-            DQ_W6_BODIES
+            {
+                // G_eff[:, i], G_eff[i, :]: the pass over the k pending pairs (walk_bodies.inc), pivot entries broadcast by DPP from pa / pb:
+                // lane r16 of every row holds {U_m[i], W_m[i]} for m = r16 (pa) and m = 16 + r16 (pb); entries m >= k are never used
+                const int kc = max(k - 1, 0);
+                const double2 pa = sh.UW[min(r16, kc) * n + i], pb = sh.UW[min(16 + r16, kc) * n + i];
+                double u1 = 0.0, w1 = 0.0;
+                DQ_W6_PAIRS;
+                uj += u1; wj += w1;
+                if (j == i) wj -= 1.0;                                           // V(i) -= 1 (source/model.cpp:135)
+                const double pu = pref * uj;
+                dg += pu * wj;
+                if (live) { sh.UW[k * n + j] = make_double2(pu, wj); (par ? sh.diag : sh.diag2)[j] = dg; }     // slot k / the diagonal buffer no wave is reading
+                if (j == 0) sh.acc_site[k] = p;                                  // fields are written at window end
+                DQ_W6_SETPAIR(pu, wj);
+            }
             DQ_ST(STAMP(t2))
             ++k; par ^= 1;
             lds_barrier();
@@ -525,7 +335,7 @@ __device__ __forceinline__ void scan_shared_init(ScanShared& sh, unsigned char* 
 // MAXT: the launch bound.  For n <= 256 the kernel runs one wave per SIMD and may use the whole 512-entry register
 // file (walk v3); under a 1024-thread bound (128 VGPRs) only the LDS variant fits.
 template <int MAXT>
-__global__ __launch_bounds__(MAXT) __attribute__((amdgpu_num_vgpr(64))) void scan_kernel(UpdateDesc d, int l, int acc_slot, int first, int kd) {
+__global__ __launch_bounds__(MAXT) DQ_WALK_REGS void scan_kernel(UpdateDesc d, int l, int acc_slot, int first, int kd) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int chain = blockIdx.y;
     const int n = d.n;
@@ -582,13 +392,8 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_num_vgpr(64))) void sca
 #endif
     if constexpr (REGS) {
         const double* __restrict__ GT = d.GT.at(chain);
-#ifdef DQ_WALK_V3
-        double dg0 = live ? sh.diag[j] : 0.0;
-        k = walk_window<false>(sh, pos, dg0, n, kd, j, live, G, GT, d, slice_off, chain, fields_g, Up, Wp PROF_PASS);
-#else
         double dg0 = live ? sh.diag[j] : 0.0;
         k = walk_window6<false>(sh, pos, dg0, n, kd, j, live, G, GT, d, slice_off, chain, fields_g, Up, Wp PROF_PASS);
-#endif
     } else {
         double pcA[SCAN_PF], prA[SCAN_PF], pcB[SCAN_PF], prB[SCAN_PF];
         int g = pos / SCAN_PF;
@@ -765,7 +570,7 @@ __device__ __attribute__((noinline)) void solo_flush(double* G, double* GT, cons
 constexpr unsigned SLICE_SPIN_LIMIT = 1u << 22;     // polls (>= 1 us each) a resident partner is given
 constexpr unsigned SLICE_CENSUS_SPINS = 256;        // polls the walk grants late flush workgroups before it goes solo (~100-200 us)
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(64))) void slice_kernel(UpdateDesc d, SliceSync* sync_p, int l, int acc_slot, int kd, int tiles_per_dim, int* info) {
+__global__ __launch_bounds__(256) DQ_WALK_REGS void slice_kernel(UpdateDesc d, SliceSync* sync_p, int l, int acc_slot, int kd, int tiles_per_dim, int* info) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int chain = blockIdx.y;
     const int n = d.n;
@@ -843,11 +648,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(64))) void slic
         ScanProf prof; unsigned long long tk0, t_hand = 0; STAMP(tk0)
 #endif
         for (unsigned win = 1;; ++win) {
-#ifdef DQ_WALK_V3
-            const int k = walk_window<true>(sh, pos, dg, n, kd, j, live, G, GT, d, slice_off, chain, fields_g, Up, Wp PROF_PASS);
-#else
             const int k = walk_window6<true>(sh, pos, dg, n, kd, j, live, G, GT, d, slice_off, chain, fields_g, Up, Wp PROF_PASS);
-#endif
             total_acc += k;
             const bool final = pos >= n;
 #ifdef DQ_SCAN_STAMPS
@@ -922,7 +723,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(64))) void slic
 }
 
 // resume = 1: finish a slice that scan / flush kernel pairs have walked up to state[0] (exits at once when nothing is left)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(64))) void slice_solo_kernel(UpdateDesc d, int l, int acc_slot, int kd, int resume) {
+__global__ __launch_bounds__(256) DQ_WALK_REGS void slice_solo_kernel(UpdateDesc d, int l, int acc_slot, int kd, int resume) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int chain = blockIdx.y;
     const int n = d.n;
@@ -957,11 +758,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(64))) void slic
     ScanProf prof;
 #endif
     for (;;) {
-#ifdef DQ_WALK_V3
-        const int k = walk_window<false, false>(sh, pos, dg, n, kd, j, live, G, GT, d, slice_off, chain, fields_g, nullptr, nullptr PROF_PASS);
-#else
         const int k = walk_window6<false, false>(sh, pos, dg, n, kd, j, live, G, GT, d, slice_off, chain, fields_g, nullptr, nullptr PROF_PASS);
-#endif
         total_acc += k;
         __syncthreads();                                              // every pair of the window is in LDS
         if (k > 0) {
