@@ -275,7 +275,7 @@ __device__ __forceinline__ int walk_window6(const ScanShared& sh, int& pos, doub
             // the pivot's G column / row elements from set gs: this group's 16 loads are done once at most the 32 younger ones are pending
             int ulo, uhi, wlo, whi;
             asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
-            if (gs == 0) { DQ_W6_PICK_0 } else if (gs == 1) { DQ_W6_PICK_1 } else { DQ_W6_PICK_2 }
+            DQ_W6_PICK(gs * 8 + first);
             double uj = __hiloint2double(uhi, ulo), wj = __hiloint2double(whi, wlo);
             DQ_ST(STAMP(t1))
             {
@@ -306,8 +306,7 @@ __device__ __forceinline__ int walk_window6(const ScanShared& sh, int& pos, doub
 #ifdef DQ_SCAN_STAMPS
     unsigned long long td0; STAMP(td0)
 #endif
-    // the prefetch loads still in flight must not land in a later window's (or the solo flush's) registers
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // (prefetch loads may still be in flight into their AGPR sets: the caller drains vmcnt before anything else can use them)
     // ---- window end: the flush's operands and the accepted field changes leave the workgroup (coalesced, from registers) ----
     if (PANELS && live) DQ_W6_DUMP;
     if (j < k) {
@@ -654,17 +653,20 @@ __global__ __launch_bounds__(256) DQ_WALK_REGS void slice_kernel(UpdateDesc d, S
 #ifdef DQ_SCAN_STAMPS
             unsigned long long th0; STAMP(th0)
 #endif
+            // census (first window): is every flush workgroup resident?  One coalesced load, issued in front of the drain of the panel
+            // stores so that its round trip hides behind theirs (the workgroups checked in while the first window was walked)
+            unsigned census = slice_tag(epoch, 0);
+            if (win == 1 && wave == 0 && lane < F) census = __hip_atomic_load(&sy->arrive[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // panel stores of every wave have left the CU
             __syncthreads();
             if (win == 1) {
-                // census: is every flush workgroup resident?  (one coalesced load; they checked in while the first window was walked)
                 if (wave == 0) {
-                    unsigned spins = 0; bool all_in = false;
-                    for (;;) {
-                        const unsigned a = lane < F ? __hip_atomic_load(&sy->arrive[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : slice_tag(epoch, 0);
-                        if (__all(a == slice_tag(epoch, 0))) { all_in = true; break; }
+                    unsigned spins = 0; bool all_in = __all(census == slice_tag(epoch, 0));
+                    while (!all_in) {
                         if (++spins > SLICE_CENSUS_SPINS) break;
                         __builtin_amdgcn_s_sleep(8);
+                        const unsigned a = lane < F ? __hip_atomic_load(&sy->arrive[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : slice_tag(epoch, 0);
+                        all_in = __all(a == slice_tag(epoch, 0));
                     }
                     if (lane == 0) *flag = all_in ? 0 : 1;
                 }
