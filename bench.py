@@ -422,8 +422,6 @@ def main():
             out["batched"] = {"chains_per_gpu": B, "engines": E, "value": B * nb / tb, "unit": "sweeps/s", "ms_per_step": 1e3 * tb / nb, "steps": nb,
                               "note": "aggregate over independent chains sharing kernel launches; not the headline config"}
             for (ee, _, _) in engs: ee.close()
-        if world == 1 and C == 1 and args.config == "cfg3" and not args.checkerboard and not args.no_cfg5:
-            out["cfg5"] = cfg5_block(lib, local_rank)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model, 12345, args.cpu_budget, lib, local_rank, args.config)
         if args.rehearse_shared_gpu:
@@ -431,6 +429,9 @@ def main():
     rex = None
     if world > 1 and C == 1 and not args.no_replica_exchange and not args.rehearse_shared_gpu:
         rex = replica_exchange_check(lib, eng, d)
+    if rank == 0 and world == 1 and C == 1 and args.config == "cfg3" and not args.checkerboard and not args.no_cfg5:
+        eng.close()                                   # hands back its CU reservation: the cfg-5 engine takes the persistent slice kernel as it does on its own
+        out["cfg5"] = cfg5_block(lib, local_rank)
     if rank == 0:
         if rex is not None:
             out["replica_exchange"] = rex
