@@ -424,7 +424,9 @@ __global__ __launch_bounds__(MAXT) DQ_WALK_REGS void scan_kernel(UpdateDesc d, i
 // and the panel rows are all loaded in ONE round trip (panel rows unconditionally for all KD slots -- stale slots are
 // masked after the fact).  The second MFMA chain (operands swapped) produces the transposed tile in the layout whose
 // stores are coalesced, instead of scattering the first chain's accumulators.
-template <bool COH, bool WITH_GT>
+// PAIRED: the panels are stored as P[m >> 1][a][m & 1] (what the register walk's window-end dump writes with 16-byte stores);
+// otherwise as P[m][a] (the LDS walk of n > 256, which stores rows as it goes).
+template <bool COH, bool WITH_GT, bool PAIRED>
 __device__ __forceinline__ void flush_tile(double* __restrict__ G, double* __restrict__ GT, const double* __restrict__ Up, const double* __restrict__ Wp,
                                            int a0, int b0, int n, int k, int kd, int lane) {
     const int r = lane & 15, kk = lane >> 4;
@@ -434,8 +436,9 @@ __device__ __forceinline__ void flush_tile(double* __restrict__ G, double* __res
 #pragma unroll
     for (int s = 0; s < UPDATE_KD / 4; ++s) {
         const int m = min(4 * s + kk, kd - 1);
-        if (COH) { wv[s] = ld_coh(Wp + m * n + b); uv[s] = ld_coh(Up + m * n + a); }
-        else { wv[s] = Wp[m * n + b]; uv[s] = Up[m * n + a]; }
+        const int ib = PAIRED ? (m >> 1) * 2 * n + 2 * b + (m & 1) : m * n + b, ia = PAIRED ? (m >> 1) * 2 * n + 2 * a + (m & 1) : m * n + a;
+        if (COH) { wv[s] = ld_coh(Wp + ib); uv[s] = ld_coh(Up + ia); }
+        else { wv[s] = Wp[ib]; uv[s] = Up[ia]; }
     }
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
@@ -473,7 +476,7 @@ __global__ __launch_bounds__(256) void flush_kernel(UpdateDesc d, int tiles_per_
     // (batched engines are bandwidth-bound here: 40 % of the flush traffic was for windows with nothing to apply)
     const int k = __builtin_amdgcn_readfirstlane(d.state[(long)chain * d.state_stride + 1]);
     if (k == 0) return;
-    flush_tile<false, WITH_GT>(d.G.at(chain), WITH_GT ? d.GT.at(chain) : nullptr, d.Upanel + (long)chain * d.panel_stride, d.Wpanel + (long)chain * d.panel_stride,
+    flush_tile<false, WITH_GT, WITH_GT>(d.G.at(chain), WITH_GT ? d.GT.at(chain) : nullptr, d.Upanel + (long)chain * d.panel_stride, d.Wpanel + (long)chain * d.panel_stride,
                                a0, b0, n, k, kd, lane);
 }
 
@@ -611,7 +614,7 @@ __global__ __launch_bounds__(256) DQ_WALK_REGS void slice_kernel(UpdateDesc d, S
             if (lo & SLICE_SOLO_BIT) break;                           // the walk applies the windows itself: G is not ours to touch
             const int k = (int)(lo & 0x3fffffffu);
             const bool final = (lo & SLICE_FINAL_BIT) != 0;
-            if (k > 0 && a0 < n && b0 < n) flush_tile<true, true>(G, GT, Up, Wp, a0, b0, n, k, kd, lane);
+            if (k > 0 && a0 < n && b0 < n) flush_tile<true, true, true>(G, GT, Up, Wp, a0, b0, n, k, kd, lane);
             if (final) break;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains before the arrival is signalled
             __syncthreads();
