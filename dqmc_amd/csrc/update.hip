@@ -207,18 +207,16 @@ __device__ __forceinline__ bool scan_group(const double (&pc)[SCAN_PF], const do
 #include "walk_bodies.inc"
 #pragma clang diagnostic ignored "-Winline-asm"
 
-// issues the loads of the 8 proposals of group g into prefetch set gs = g % 3 (AGPRs; nothing waits here).  Addresses: the column
-// base G + n * site * 8 is wave-uniform (scalar ALU, from one lane-distributed LDS read of the group's sites), the lane adds j * 8.
+// issues the loads of the 8 proposals of group g into prefetch set gs = g % 3 (AGPRs; nothing waits here).  Addresses: constant
+// scalar bases G / GT + a 32-bit lane offset (j + n * site) * 8, the column part n * site * 8 formed on the scalar ALU from one
+// lane-distributed LDS read of the group's sites (three instructions per proposal in front of its two loads).
 template <bool COH>
 __device__ __forceinline__ void walk6_load_group(const double* __restrict__ G, const double* __restrict__ GT, const ScanShared& sh, int g, int gs, int n, int j, bool live) {
-    const unsigned jj8 = (unsigned)(live ? j : n - 1) * 8u;
+    const unsigned jj8 = (unsigned)(live ? j : n - 1) * 8u, n8 = (unsigned)n * 8u;
     const int ig = sh.site[min(g * 8 + (int)(threadIdx.x & 7), n - 1)];       // lane q (mod 8): site of proposal 8 g + q, clamped: loads stay unconditional
-    const char* gcol[8]; const char* tcol[8];
+    unsigned off8[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const size_t off = (size_t)((unsigned)__builtin_amdgcn_readlane(ig, q) * (unsigned)n) * 8u;
-        gcol[q] = reinterpret_cast<const char*>(G) + off; tcol[q] = reinterpret_cast<const char*>(GT) + off;
-    }
+    for (int q = 0; q < 8; ++q) off8[q] = jj8 + (unsigned)__builtin_amdgcn_readlane(ig, q) * n8;
     if (gs == 0) { if (COH) { DQ_W6_LOADSET_0_COH } else { DQ_W6_LOADSET_0_PLAIN } }
     else if (gs == 1) { if (COH) { DQ_W6_LOADSET_1_COH } else { DQ_W6_LOADSET_1_PLAIN } }
     else { if (COH) { DQ_W6_LOADSET_2_COH } else { DQ_W6_LOADSET_2_PLAIN } }
