@@ -91,7 +91,7 @@ __device__ __forceinline__ void scan_prefetch(double (&pc)[SCAN_PF], double (&pr
 // processes the proposals of group g from position `pos` on; returns false when the window is full or the walk is over
 #ifdef DQ_SCAN_STAMPS
 #define STAMP(v) { unsigned long long _t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t) :: "memory"); v = _t; }
-struct ScanProf { unsigned long long t_rej = 0, t_kloop = 0, t_tail = 0, t_wait = 0, t_first = 0, t_dump = 0, t_noacc = 0; int n_rej = 0, n_acc = 0, n_noacc = 0; };
+struct ScanProf { unsigned long long t_rej = 0, t_kloop = 0, t_tail = 0, t_wait = 0, t_first = 0, t_dump = 0, t_noacc = 0, t_pub = 0, t_fin = 0, t_finwait = 0; int n_rej = 0, n_acc = 0, n_noacc = 0, n_pub = 0, n_fin_k = 0, n_fin_g = 0, n_fin_e = 0; };
 #define PROF_ARG , ScanProf& prof
 #else
 #define PROF_ARG
@@ -185,7 +185,7 @@ __device__ __forceinline__ bool scan_group(const double (&pc)[SCAN_PF], const do
 }
 
 
-#define DQ_WALK_REGS __attribute__((amdgpu_num_vgpr(64)))     // allocator confined to v0..v127: v128..v255 and a0..a95 are the walk's (walk_bodies.inc)
+#define DQ_WALK_REGS __attribute__((amdgpu_num_vgpr(128)))    // allocator confined to v0..v127 and a0..a127: v128..v255 and a128..a223 are the walk's (walk_bodies.inc; checked on the ISA by scripts/check_walk_regs.py)
 // ---- the Metropolis walk of one window (n <= 256: one wave per SIMD) ------------------------------------------------------------
 // Per accepted flip the walk needs u = G_eff[:, i] and w = G_eff[i, :] - e_i of the effective Green's function
 // G_eff = G + sum_m U_m W_m^T (delayed updates): one pass over the k <= 32 pending pairs.  How it is organised, and why (round-3
@@ -194,7 +194,7 @@ __device__ __forceinline__ bool scan_group(const double (&pc)[SCAN_PF], const do
 //     the first accepted one are discarded because the diagonal changes, rejected ones before it are exact;
 //   * a lane's own pairs {U_m[j], W_m[j]} and the prefetched G column / row elements of three groups of 8 proposals live in
 //     registers the allocator never sees (walk_bodies.inc, generated: literal register names, kernels compiled with
-//     amdgpu_num_vgpr(64)).  Left to the allocator they were the walk's main cost: as vectors with a dynamic slot index, 24
+//     amdgpu_num_vgpr(128)).  Left to the allocator they were the walk's main cost: as vectors with a dynamic slot index, 24
 //     s_set_gpr_idx mode switches + 16 moves + 8 selects per flip; as named scalars behind a dispatch on k, ~70 reconciliation moves
 //     at the joins and one prefetch set loaded into temporaries behind s_waitcnt vmcnt(0);
 //   * the pass over the pairs is ONE chain of 2 x 32 v_fmac_f64_dpp (pivot entries {U_m[i], W_m[i]}: two compact LDS reads, lane r
@@ -204,6 +204,13 @@ __device__ __forceinline__ bool scan_group(const double (&pc)[SCAN_PF], const do
 //     younger groups' 32 loads may still be in flight); the row G[site, :] is read from the transposed copy GT (coalesced);
 //   * NO global store inside the walk: panel rows, fields and exp(V) entries are written when the window closes; barriers order
 //     LDS only; the diagonal is double-buffered in LDS (one barrier per accepted flip).
+#ifndef DQ_W6_KPUB
+#define DQ_W6_KPUB 24        // asynchronous windows: pairs per publish ...
+#define DQ_W6_XOVER 8        // ... and accepted flips the walk goes on for before it waits for their flush (SliceAsync)
+#endif
+#define DQ_W6_CAT2(a, b) a##b
+#define DQ_W6_CAT(a, b) DQ_W6_CAT2(a, b)
+#define DQ_W6_REBASE DQ_W6_CAT(DQ_W6_REBASE_, DQ_W6_KPUB)
 #include "walk_bodies.inc"
 #pragma clang diagnostic ignored "-Winline-asm"
 
@@ -222,13 +229,91 @@ __device__ __forceinline__ void walk6_load_group(const double* __restrict__ G, c
     else { if (COH) { DQ_W6_LOADSET_2_COH } else { DQ_W6_LOADSET_2_PLAIN } }
 }
 
-template <bool COH, bool PANELS = true>
+constexpr unsigned SLICE_SPIN_LIMIT = 1u << 22;     // polls (>= 1 us each) a resident partner is given
+constexpr unsigned SLICE_CENSUS_SPINS = 256;        // polls the walk grants late flush workgroups before it goes solo (~100-200 us)
+
+__device__ __attribute__((noinline)) void solo_flush(double* G, double* GT, const double2* UW, int n, int k);
+// ---- the walk workgroup's side of the persistent kernel's hand-off (protocol: see slice_kernel) ----
+// census: has every flush workgroup checked in?  `first` is wave 0's load of the check-in words issued ahead of the caller's drain.
+// Returns true when some are still missing after the bounded wait (the walk then goes solo).  Block-wide (two barriers).
+__device__ __forceinline__ bool slice_census_missing(SliceSync* sy, unsigned epoch, int F, unsigned first, int* flag) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (wave == 0) {
+        unsigned spins = 0; bool all_in = __all(first == slice_tag(epoch, 0));
+        while (!all_in) {
+            if (++spins > SLICE_CENSUS_SPINS) break;
+            __builtin_amdgcn_s_sleep(8);
+            const unsigned a = lane < F ? __hip_atomic_load(&sy->arrive[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : slice_tag(epoch, 0);
+            all_in = __all(a == slice_tag(epoch, 0));
+        }
+        if (lane == 0) *flag = all_in ? 0 : 1;
+    }
+    __syncthreads();
+    const bool missing = *flag != 0;
+    __syncthreads();
+    return missing;
+}
+// wait until every tile has absorbed window `win` (wave 0 polls, lane f <-> flush workgroup f, F <= 64: one coalesced load per poll)
+__device__ __forceinline__ void slice_wait_arrivals(SliceSync* sy, unsigned epoch, unsigned win, int F, int* info) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (wave == 0) {
+        unsigned spins = 0; bool broken = false;
+        for (;;) {
+            const unsigned a = lane < F ? __hip_atomic_load(&sy->arrive[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : slice_tag(epoch, win);
+            if (__all(a == slice_tag(epoch, win))) break;
+            if (++spins > SLICE_SPIN_LIMIT) { broken = true; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (broken && lane == 0) { __hip_atomic_store(&sy->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (info) atomicOr(info, 4); }
+    }
+    __syncthreads();
+}
+
+// Asynchronous windows (persistent kernel only).  The walk itself publishes its first DQ_W6_KPUB = 24 pairs and KEEPS WALKING while the
+// flush workgroups apply them: its view G_eff = G_old + all pending pairs does not depend on when the 24 land in memory, as long as it
+// reads no element of G meanwhile -- it lives on the columns already prefetched from G_old (the rest of this group and the next two)
+// and on room for 8 more pairs.  When either runs out, or the slice ends, it waits for the arrivals (by then mostly there), drops the
+// 24 applied pairs (registers and LDS rows 24 .. k-1 move down to 0 ..), and restarts the prefetch from the new G.
+struct NoAsync { static constexpr bool enabled = false; };
+__device__ __forceinline__ bool as_inflight(const NoAsync&) { return false; }
+struct SliceAsync {
+    static constexpr bool enabled = true;
+    SliceSync* sy; unsigned epoch; int F; int* info; int* flag;
+    unsigned win = 1;            // number of the next window to be published
+    int published = 0;           // pairs handed off inside the walk (the caller's acceptance count)
+    bool solo = false;
+    bool inflight = false;       // a published window has not been waited for yet
+    int g_limit = 0;             // last group whose columns were prefetched before the publish
+};
+
+__device__ __forceinline__ bool as_inflight(const SliceAsync& a) { return a.inflight; }
+
+template <bool COH, bool PANELS = true, class AS = NoAsync>
 __device__ __forceinline__ int walk_window6(const ScanShared& sh, int& pos, double& dg, int n, int kd, int j, bool live, const double* __restrict__ G,
                                             const double* __restrict__ GT, const UpdateDesc& d, long slice_off, int chain, int8_t* fields_g,
-                                            double* __restrict__ Up, double* __restrict__ Wp PROF_ARG) {
+                                            double* __restrict__ Up, double* __restrict__ Wp, AS& as PROF_ARG) {
     const int lane = threadIdx.x & 63, r16 = lane & 15, q8 = lane & 7;
     DQ_W6_RESERVE;
     int par = 0, k = 0;
+#ifdef DQ_SCAN_STAMPS
+#define DQ_ST(...) __VA_ARGS__
+#else
+#define DQ_ST(...)
+#endif
+    // the published window has been applied: forget its pairs.  Block-wide; ends with every wave past a barrier
+    auto async_finish = [&]() {
+        if constexpr (AS::enabled) {
+            DQ_ST(unsigned long long tf0, tf1, tf2; STAMP(tf0))
+            slice_wait_arrivals(as.sy, as.epoch, as.win, as.F, as.info);
+            DQ_ST(STAMP(tf1))
+            DQ_W6_REBASE;
+            if (live) for (int t = 0; t < k - DQ_W6_KPUB; ++t) sh.UW[t * n + j] = sh.UW[(DQ_W6_KPUB + t) * n + j];
+            if (j < k - DQ_W6_KPUB) sh.acc_site[j] = sh.acc_site[DQ_W6_KPUB + j];
+            k -= DQ_W6_KPUB; ++as.win; as.inflight = false;
+            lds_barrier();
+            DQ_ST(STAMP(tf2) prof.t_finwait += tf1 - tf0; prof.t_fin += tf2 - tf1;)
+        }
+    };
     int g = pos >> 3;
     bool done = false;
     // no vector-memory operation of this workgroup may be in flight when the counted waits below start counting.  Twice on purpose:
@@ -239,14 +324,18 @@ __device__ __forceinline__ int walk_window6(const ScanShared& sh, int& pos, doub
     __builtin_amdgcn_s_waitcnt(0x0F70);                                        // vmcnt(0), expcnt / lgkmcnt untouched
     walk6_load_group<COH>(G, GT, sh, g, g % 3, n, j, live);
     walk6_load_group<COH>(G, GT, sh, g + 1, (g + 1) % 3, n, j, live);
-#ifdef DQ_SCAN_STAMPS
-#define DQ_ST(...) __VA_ARGS__
-#else
-#define DQ_ST(...)
-#endif
     while (!done) {
         DQ_ST(unsigned long long tg0, tg1; STAMP(tg0))
         const int gs = g % 3;                                                  // register set of this group
+        if constexpr (AS::enabled) {
+            if (as.inflight && g > as.g_limit) {                               // out of columns of the old G
+                DQ_ST(prof.n_fin_g++;)
+                async_finish();
+                walk6_load_group<COH>(G, GT, sh, g, gs, n, j, live);
+                walk6_load_group<COH>(G, GT, sh, g + 1, (g + 1) % 3, n, j, live);
+            }
+            if (!as.inflight) walk6_load_group<COH>(G, GT, sh, g + 2, (g + 2) % 3, n, j, live);
+        } else
         walk6_load_group<COH>(G, GT, sh, g + 2, (g + 2) % 3, n, j, live);
         DQ_ST(STAMP(tg1) prof.t_first += tg1 - tg0;)
         const int gbase = g * 8;
@@ -270,17 +359,20 @@ __device__ __forceinline__ int walk_window6(const ScanShared& sh, int& pos, doub
             pos = p + 1;
             const int i = __builtin_amdgcn_readlane(i_l, first);
             const double pref = readlane_f64(pref_l, first);
+            // pivot entries of the pending pairs, broadcast by DPP in the pass below: lane r16 of every row holds {U_m[i], W_m[i]} for
+            // m = r16 (pa) and m = 16 + r16 (pb); entries m >= k are never used.  Read here, in front of the asm statements (their
+            // "memory" clobbers pin LDS reads behind them): the LDS latency runs under the wait and the pick
+            const int kc = max(k - 1, 0);
+            const double2 pa = sh.UW[min(r16, kc) * n + i], pb = sh.UW[min(16 + r16, kc) * n + i];
             // the pivot's G column / row elements from set gs: this group's 16 loads are done once at most the 32 younger ones are pending
             int ulo, uhi, wlo, whi;
-            asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+            if (AS::enabled && as_inflight(as)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (nothing is in flight then: the publish drained)
+            else asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
             DQ_W6_PICK(gs * 8 + first);
             double uj = __hiloint2double(uhi, ulo), wj = __hiloint2double(whi, wlo);
             DQ_ST(STAMP(t1))
             {
-                // G_eff[:, i], G_eff[i, :]: the pass over the k pending pairs (walk_bodies.inc), pivot entries broadcast by DPP from pa / pb:
-                // lane r16 of every row holds {U_m[i], W_m[i]} for m = r16 (pa) and m = 16 + r16 (pb); entries m >= k are never used
-                const int kc = max(k - 1, 0);
-                const double2 pa = sh.UW[min(r16, kc) * n + i], pb = sh.UW[min(16 + r16, kc) * n + i];
+                // G_eff[:, i], G_eff[i, :]: the pass over the k pending pairs (walk_bodies.inc), pivot entries broadcast by DPP from pa / pb
                 double u1 = 0.0, w1 = 0.0;
                 DQ_W6_PAIRS;
                 uj += u1; wj += w1;
@@ -295,11 +387,58 @@ __device__ __forceinline__ int walk_window6(const ScanShared& sh, int& pos, doub
             ++k; par ^= 1;
             lds_barrier();
             DQ_ST(STAMP(t3) prof.t_wait += t1 - t0; prof.t_kloop += t2 - t1; prof.t_tail += t3 - t2; prof.n_acc++;)
+            if constexpr (AS::enabled) {
+                if (k == DQ_W6_KPUB && kd == UPDATE_KD && !as.inflight && !as.solo && pos < n) {
+                    // ---- publish pairs 0 .. 23 and walk on ----
+                    DQ_ST(unsigned long long tp0, tp1; STAMP(tp0))
+                    if (live) DQ_W6_DUMP_PUB;
+                    if (j < DQ_W6_KPUB) {
+                        const int pp = sh.acc_site[j];
+                        const int ii = sh.site[pp], new_f = sh.newf[pp];
+                        fields_g[ii] = (int8_t)new_f;
+                        d.expv[(long)chain * d.v_stride + slice_off + ii] = sh.tl[24 + new_f];
+                        d.invexpv[(long)chain * d.v_stride + slice_off + ii] = sh.tl[28 + new_f];
+                    }
+                    unsigned census = slice_tag(as.epoch, 0);
+                    if (as.win == 1 && threadIdx.x < (unsigned)as.F) census = __hip_atomic_load(&as.sy->arrive[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // panel stores (and the youngest prefetch loads) of every wave are done
+                    __syncthreads();
+                    if (as.win == 1 && slice_census_missing(as.sy, as.epoch, as.F, census, as.flag)) {
+                        // some flush workgroup is not resident: nobody else will touch G in this launch
+                        as.solo = true;
+                        if (threadIdx.x == 0) {
+                            __hip_atomic_store(&as.sy->seq, ((unsigned long long)slice_tag(as.epoch, as.win) << 32) | SLICE_SOLO_BIT | (unsigned)k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_fetch_add(&as.sy->solo_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                        solo_flush(const_cast<double*>(G), const_cast<double*>(GT), sh.UW, n, k);
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        __syncthreads();
+                        as.published += k; k = 0; ++as.win;
+                        walk6_load_group<COH>(G, GT, sh, g, gs, n, j, live);
+                        walk6_load_group<COH>(G, GT, sh, g + 1, (g + 1) % 3, n, j, live);
+                        walk6_load_group<COH>(G, GT, sh, g + 2, (g + 2) % 3, n, j, live);
+                    } else {
+                        if (threadIdx.x == 0)
+                            __hip_atomic_store(&as.sy->seq, ((unsigned long long)slice_tag(as.epoch, as.win) << 32) | (unsigned)DQ_W6_KPUB, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        as.published += DQ_W6_KPUB; as.inflight = true; as.g_limit = g + 2;
+                    }
+                    DQ_ST(STAMP(tp1) prof.t_pub += tp1 - tp0; prof.n_pub++;)
+                }
+                if (k >= kd || (as.inflight && k >= DQ_W6_KPUB + DQ_W6_XOVER)) {
+                    if (!as.inflight) { done = true; break; }
+                    DQ_ST(prof.n_fin_k++;)
+                    async_finish();                                            // room for pairs again; this group's columns from the new G
+                    walk6_load_group<COH>(G, GT, sh, g, gs, n, j, live);
+                    walk6_load_group<COH>(G, GT, sh, g + 1, (g + 1) % 3, n, j, live);
+                    walk6_load_group<COH>(G, GT, sh, g + 2, (g + 2) % 3, n, j, live);
+                }
+            } else
             if (k >= kd) { done = true; break; }
         }
         if (pos >= n) done = true;
         ++g;
     }
+    if constexpr (AS::enabled) { if (as.inflight) { DQ_ST(prof.n_fin_e++;) async_finish(); } }
 #undef DQ_ST
 #ifdef DQ_SCAN_STAMPS
     unsigned long long td0; STAMP(td0)
@@ -390,7 +529,7 @@ __global__ __launch_bounds__(MAXT) DQ_WALK_REGS void scan_kernel(UpdateDesc d, i
     if constexpr (REGS) {
         const double* __restrict__ GT = d.GT.at(chain);
         double dg0 = live ? sh.diag[j] : 0.0;
-        k = walk_window6<false>(sh, pos, dg0, n, kd, j, live, G, GT, d, slice_off, chain, fields_g, Up, Wp PROF_PASS);
+        { NoAsync na; k = walk_window6<false>(sh, pos, dg0, n, kd, j, live, G, GT, d, slice_off, chain, fields_g, Up, Wp, na PROF_PASS); }
     } else {
         double pcA[SCAN_PF], prA[SCAN_PF], pcB[SCAN_PF], prB[SCAN_PF];
         int g = pos / SCAN_PF;
@@ -567,8 +706,6 @@ __device__ __attribute__((noinline)) void solo_flush(double* G, double* GT, cons
     const int tiles16 = (n + 15) / 16, n_st = tiles16 * tiles16;
     for (int st = wave; st < n_st; st += 4 * 4) flush_tiles_lds<4>(G, GT, UW, st, 4, n_st, tiles16, n, k, lane);
 }
-constexpr unsigned SLICE_SPIN_LIMIT = 1u << 22;     // polls (>= 1 us each) a resident partner is given
-constexpr unsigned SLICE_CENSUS_SPINS = 256;        // polls the walk grants late flush workgroups before it goes solo (~100-200 us)
 
 __global__ __launch_bounds__(256) DQ_WALK_REGS void slice_kernel(UpdateDesc d, SliceSync* sync_p, int l, int acc_slot, int kd, int tiles_per_dim, int* info) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -642,14 +779,16 @@ __global__ __launch_bounds__(256) DQ_WALK_REGS void slice_kernel(UpdateDesc d, S
         if (j < 32) sh.tl[j] = tab_g[j];
         __syncthreads();
         int pos = 0, total_acc = 0;
-        bool solo = false;
         int* flag = sh.acc_site + UPDATE_KD;                          // spare LDS word behind acc_site: wave 0's verdict on the census
 #ifdef DQ_SCAN_STAMPS
         ScanProf prof; unsigned long long tk0, t_hand = 0; STAMP(tk0)
 #endif
-        for (unsigned win = 1;; ++win) {
-            const int k = walk_window6<true>(sh, pos, dg, n, kd, j, live, G, GT, d, slice_off, chain, fields_g, Up, Wp PROF_PASS);
-            total_acc += k;
+        SliceAsync as{sy, epoch, F, info, flag};
+        for (;; ++as.win) {
+            const int k = walk_window6<true, true, SliceAsync>(sh, pos, dg, n, kd, j, live, G, GT, d, slice_off, chain, fields_g, Up, Wp, as PROF_PASS);
+            total_acc += k + as.published; as.published = 0;
+            const unsigned win = as.win;
+            bool solo = as.solo;
             const bool final = pos >= n;
 #ifdef DQ_SCAN_STAMPS
             unsigned long long th0; STAMP(th0)
@@ -660,21 +799,7 @@ __global__ __launch_bounds__(256) DQ_WALK_REGS void slice_kernel(UpdateDesc d, S
             if (win == 1 && wave == 0 && lane < F) census = __hip_atomic_load(&sy->arrive[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // panel stores of every wave have left the CU
             __syncthreads();
-            if (win == 1) {
-                if (wave == 0) {
-                    unsigned spins = 0; bool all_in = __all(census == slice_tag(epoch, 0));
-                    while (!all_in) {
-                        if (++spins > SLICE_CENSUS_SPINS) break;
-                        __builtin_amdgcn_s_sleep(8);
-                        const unsigned a = lane < F ? __hip_atomic_load(&sy->arrive[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : slice_tag(epoch, 0);
-                        all_in = __all(a == slice_tag(epoch, 0));
-                    }
-                    if (lane == 0) *flag = all_in ? 0 : 1;
-                }
-                __syncthreads();
-                solo = *flag != 0;
-                __syncthreads();
-            }
+            if (win == 1) { solo = slice_census_missing(sy, epoch, F, census, flag); as.solo = solo; }
             if (t == 0) {
                 __hip_atomic_store(&sy->seq, ((unsigned long long)slice_tag(epoch, win) << 32) | (final ? SLICE_FINAL_BIT : 0u) | (solo ? SLICE_SOLO_BIT : 0u) | (unsigned)k,
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -692,18 +817,7 @@ __global__ __launch_bounds__(256) DQ_WALK_REGS void slice_kernel(UpdateDesc d, S
                 continue;
             }
             if (final) break;
-            // wait until every tile has absorbed this window
-            if (wave == 0) {
-                unsigned spins = 0; bool broken = false;
-                for (;;) {                                            // lane f <-> flush workgroup f (F <= 64): one coalesced load per poll
-                    const unsigned a = lane < F ? __hip_atomic_load(&sy->arrive[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : slice_tag(epoch, win);
-                    if (__all(a == slice_tag(epoch, win))) break;
-                    if (++spins > SLICE_SPIN_LIMIT) { broken = true; break; }
-                    __builtin_amdgcn_s_sleep(1);
-                }
-                if (broken && lane == 0) { __hip_atomic_store(&sy->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (info) atomicOr(info, 4); }
-            }
-            __syncthreads();
+            slice_wait_arrivals(sy, epoch, win, F, info);                // until every tile has absorbed this window
             // G changed: the prefetch restarts from memory.  The diagonal does not: the lane's running value dg (advanced by pu * wj at
             // every accepted flip) IS G_jj after the flush up to the summation order, so the next window starts from it instead of
             // paying an L2 round trip in front of the prefetch (it is re-read from G at the start of every slice)
@@ -717,8 +831,9 @@ __global__ __launch_bounds__(256) DQ_WALK_REGS void slice_kernel(UpdateDesc d, S
 #ifdef DQ_SCAN_STAMPS
         if (j == 0) { unsigned long long tk1; STAMP(tk1)
 #if 1
-            printf("slice l=%d: total %llu cyc | hand-offs %llu | %d acc: decide+fetch %llu pairs %llu tail %llu | window start->first flip %llu | %d empty passes %llu | dump+drain %llu\n",
-                   l, tk1 - tk0, t_hand, prof.n_acc, prof.t_wait, prof.t_kloop, prof.t_tail, prof.t_first, prof.n_noacc, prof.t_noacc, prof.t_dump);
+            printf("slice l=%d: total %llu cyc | hand-offs %llu | %d acc: decide+fetch %llu pairs %llu tail %llu | window start->first flip %llu | %d empty passes %llu | dump+drain %llu | %d async publishes %llu, finishes (full %d / columns %d / end %d): wait %llu rebase %llu\n",
+                   l, tk1 - tk0, t_hand, prof.n_acc, prof.t_wait, prof.t_kloop, prof.t_tail, prof.t_first, prof.n_noacc, prof.t_noacc, prof.t_dump,
+                   prof.n_pub, prof.t_pub, prof.n_fin_k, prof.n_fin_g, prof.n_fin_e, prof.t_finwait, prof.t_fin);
 #endif
         }
 #endif
@@ -761,7 +876,7 @@ __global__ __launch_bounds__(256) DQ_WALK_REGS void slice_solo_kernel(UpdateDesc
     ScanProf prof;
 #endif
     for (;;) {
-        const int k = walk_window6<false, false>(sh, pos, dg, n, kd, j, live, G, GT, d, slice_off, chain, fields_g, nullptr, nullptr PROF_PASS);
+        NoAsync na; const int k = walk_window6<false, false>(sh, pos, dg, n, kd, j, live, G, GT, d, slice_off, chain, fields_g, nullptr, nullptr, na PROF_PASS);
         total_acc += k;
         __syncthreads();                                              // every pair of the window is in LDS
         if (k > 0) {

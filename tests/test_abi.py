@@ -52,3 +52,17 @@ def test_product_does_not_reference_oracle():
                 if re.search(r"(import\s+oracle|from\s+oracle|libdqmc_oracle|orc_[a-z_]+\s*\()", txt):
                     bad.append(fn)
     assert not bad, bad
+
+
+def test_walk_kernels_leave_the_hand_managed_registers_alone():
+    """The delayed-update walk keeps its pending pairs and prefetched columns in registers named literally in inline asm
+    (scripts/gen_walk_bodies.py); the allocator is kept out of them by the kernels' register budget, which only the ISA can confirm."""
+    import shutil
+    import subprocess
+    import sys
+    hipcc = os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "bin", "hipcc")
+    if not (os.path.exists(hipcc) or shutil.which("hipcc")):
+        pytest.skip("no hipcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "check_walk_regs.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
