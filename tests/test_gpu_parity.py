@@ -164,6 +164,35 @@ def test_wrap_and_slice_update(hip, orc):
     assert (e.get_fields() == o.get_fields()).all() and close(e.get_G(), o.get_G(), 1e-9)
 
 
+@pytest.mark.parametrize("pattern", ["all", "none", "first24", "first25", "every3rd", "bursts", "random"])
+def test_asynchronous_windows_of_the_slice_kernel(hip, orc, pattern):
+    """N = 256: the persistent slice kernel publishes its first 24 pending pairs and keeps walking on the columns it has already
+    prefetched (update.hip, SliceAsync).  The acceptance pattern decides which way a window ends -- pair store full, prefetched columns
+    used up, slice over -- so the uniform stream is forced: u = -1 accepts a proposal whatever its ratio, u = 1 rejects it (both
+    engines see the same stream; include/utility.h:34-37 draws u < p).  Fields bit-identical, G to the stated tolerance, slice by slice."""
+    m = HubbardModel(L1=16, L2=16, U=8.0, beta=1.0, nt=10, n_stab=5); f = m.random_fields(21)
+    e = m.engine(hip); e.set_fields(f); e.init()
+    o = m.engine(orc); o.set_fields(f); o.init()
+    rng = np.random.default_rng(5); n = m.n
+    for l in (0, 1, 2):
+        e.wrap_forward(l); o.wrap_forward(l)
+        perm, k, u = m.random_stream(rng, 1)
+        force = np.ones(n)
+        if pattern == "all": force[:] = -1.0
+        elif pattern == "first24": force[:24] = -1.0                          # exactly one publish-sized window, nothing after it
+        elif pattern == "first25": force[:25] = -1.0                          # one flip after the publish, then rejections to the end
+        elif pattern == "every3rd": force[::3] = -1.0                         # the prefetched columns run out before the pair store does
+        elif pattern == "bursts": force[40:72] = -1.0; force[200:256] = -1.0  # a full window in the middle, a burst that ends the slice
+        elif pattern == "random": force = u[0] if u.ndim == 2 else u
+        uu = np.broadcast_to(force, u.shape).copy()
+        na, no = e.local_update_slice(l, perm, k, uu), o.local_update_slice(l, perm, k, uu)
+        assert na == no
+        if pattern not in ("random",): assert na == int((force < 0).sum())
+        assert (e.get_fields() == o.get_fields()).all()
+        assert close(e.get_G(), o.get_G(), 1e-9 if pattern in ("all", "bursts") else TOL)
+    e.close()
+
+
 @pytest.mark.parametrize("cfg,n_sweeps", [("cfg1", 3), ("cfg2", 3)])
 def test_sweep_parity(hip, orc, cfg, n_sweeps):
     m = HubbardModel(**CONFIGS[cfg]); f = m.random_fields(7)
@@ -669,12 +698,16 @@ def test_bitwise_reproducible_at_full_size(hip):
     assert res[0][2] == res[1][2] and res[0][3] == res[1][3] and res[0][4] == res[1][4]
 
 
-def test_persistent_slice_kernel_survives_a_workgroup_that_never_becomes_resident(hip, orc, monkeypatch):
+@pytest.mark.parametrize("where", ["window_end", "inside_the_walk"])
+def test_persistent_slice_kernel_survives_a_workgroup_that_never_becomes_resident(hip, orc, monkeypatch, where):
     """The persistent slice kernel checks residency instead of assuming it (update.hip: census before the first publish).  With the
     test hook DQMC_DEBUG_SLICE_ABSENT one flush workgroup leaves at once without checking in -- what a workgroup that never becomes
     resident looks like to the others: the walk must notice before it has published anything, walk the slice solo (its own flushes)
-    and end with fields and G equal to the oracle's; no error is returned and the Markov trajectory is kept."""
-    m = HubbardModel(**CONFIGS["cfg2"]); rng = np.random.default_rng(77)
+    and end with fields and G equal to the oracle's; no error is returned and the Markov trajectory is kept.  Two places take the
+    census: the end of the first window (slices with fewer than 24 accepted flips: cfg 2, N = 64) and the asynchronous publish inside
+    the walk (N = 256, ~100 accepted flips per slice)."""
+    m = HubbardModel(**CONFIGS["cfg2"]) if where == "window_end" else HubbardModel(L1=16, L2=16, U=8.0, beta=1.0, nt=10, n_stab=5)
+    rng = np.random.default_rng(77)
     f0 = m.random_fields(5); sf, sb = m.random_stream(rng), m.random_stream(rng)
     monkeypatch.setenv("DQMC_DEBUG_SLICE_ABSENT", "2")            # read when the engine is created
     e = m.engine(hip)
