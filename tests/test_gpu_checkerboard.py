@@ -146,7 +146,7 @@ def test_host_facade_switch_reaches_the_engine(hip, orc):
         assert close(got["G"], o.get_G())
         d = m.engine(orc); d.set_fields(got["fields"]); d.init()
         assert np.abs(got["G"] - d.get_G()).max() > 1e-6
-        pt.sweeps(1, concurrently=False)
+        pt.sweeps(1)
         assert pt.max_err(0) < 1e-6
     finally:
         pt.close()
