@@ -707,10 +707,16 @@ __device__ __attribute__((noinline)) void solo_flush(double* G, double* GT, cons
     for (int st = wave; st < n_st; st += 4 * 4) flush_tiles_lds<4>(G, GT, UW, st, 4, n_st, tiles16, n, k, lane);
 }
 
-__global__ __launch_bounds__(256) DQ_WALK_REGS void slice_kernel(UpdateDesc d, SliceSync* sync_p, int l, int acc_slot, int kd, int tiles_per_dim, int* info) {
+// NFIX / KFIX: matrix size and window depth as compile-time constants (0 = taken from the arguments).  The headline size N = 256, kd = 32
+// gets its own instance: the LDS layout, the strides of the pair store and the tile grid become literals, which frees the scalar
+// registers the generic instance spills to VGPR lanes in the walk's loops (53 spilled SGPRs, ~1.8 us per slice)
+template <int NFIX, int KFIX>
+__global__ __launch_bounds__(256) DQ_WALK_REGS void slice_kernel(UpdateDesc d, SliceSync* sync_p, int l, int acc_slot, int kd_arg, int tiles_arg, int* info) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int chain = blockIdx.y;
-    const int n = d.n;
+    const int n = NFIX ? NFIX : d.n;
+    const int kd = KFIX ? KFIX : kd_arg;
+    const int tiles_per_dim = NFIX ? (NFIX + 31) / 32 : tiles_arg;
     const int F = tiles_per_dim * tiles_per_dim;
     SliceSync* sy = sync_p + chain;
     double* __restrict__ G = d.G.at(chain);
@@ -936,7 +942,8 @@ void slice_release(int device, int n, int n_chains) {
 int update_init_device() {
     DQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(scan_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     DQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(scan_kernel<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    DQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(slice_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    DQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(slice_kernel<0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    DQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(slice_kernel<256, UPDATE_KD>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     DQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(slice_solo_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     return 0;
 }
@@ -964,8 +971,12 @@ int launch_update_slice(const UpdateDesc& d, int l, int acc_slot, int n_chains, 
         return launch_update_slice_sm(d, l, acc_slot, n_chains, s);
     }
     if (!multi_kernel && regs && d.slice_sync) {                    // slice_sync is only handed out with a CU reservation (slice_reserve)
-        hipLaunchKernelGGL(slice_kernel, dim3(1 + tiles * tiles, n_chains), dim3(256), lds, s, d, reinterpret_cast<SliceSync*>(d.slice_sync), l, acc_slot, kd,
-                           tiles, d.info);
+        if (n == 256 && kd == UPDATE_KD)
+            hipLaunchKernelGGL((slice_kernel<256, UPDATE_KD>), dim3(1 + tiles * tiles, n_chains), dim3(256), lds, s, d, reinterpret_cast<SliceSync*>(d.slice_sync), l, acc_slot, kd,
+                               tiles, d.info);
+        else
+            hipLaunchKernelGGL((slice_kernel<0, 0>), dim3(1 + tiles * tiles, n_chains), dim3(256), lds, s, d, reinterpret_cast<SliceSync*>(d.slice_sync), l, acc_slot, kd,
+                               tiles, d.info);
         DQ_HIP(hipGetLastError());
         return 0;
     }
