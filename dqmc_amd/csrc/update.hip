@@ -348,7 +348,6 @@ __device__ __forceinline__ int walk_window6(const ScanShared& sh, int& pos, doub
             // decisions for the (remaining) proposals of the group under the current diagonal: lane q <-> proposal gbase + q
             const double* dcur = par ? sh.diag2 : sh.diag;
             const double r_l = 1.0 + (1.0 - dcur[i_l]) * dl_l;                  // det ratio per flavour (source/model.cpp:95)
-            const double pref_l = dl_l / r_l;                                    // source/model.cpp:132 (IEEE division; a v_rcp_f64 + Newton form hoisted in front of the ballot measured 0.6 % slower)
             const double R_l = rb_l * (r_l * r_l);                               // :121
             // bernoulli(min(1,|R|)): u < p (source/update.cpp:24, include/utility.h:34-37)
             const bool acc_l = p_l >= pos && p_l < n && ur_l < fmin(1.0, fabs(R_l));
@@ -358,16 +357,16 @@ __device__ __forceinline__ int walk_window6(const ScanShared& sh, int& pos, doub
             const int p = gbase + first;
             pos = p + 1;
             const int i = __builtin_amdgcn_readlane(i_l, first);
-            const double pref = readlane_f64(pref_l, first);
+            const double dl_p = readlane_f64(dl_l, first), r_p = readlane_f64(r_l, first);
             // pivot entries of the pending pairs, broadcast by DPP in the pass below: lane r16 of every row holds {U_m[i], W_m[i]} for
             // m = r16 (pa) and m = 16 + r16 (pb); entries m >= k are never used.  Read here, in front of the asm statements (their
             // "memory" clobbers pin LDS reads behind them): the LDS latency runs under the wait and the pick
             const int kc = max(k - 1, 0);
             const double2 pa = sh.UW[min(r16, kc) * n + i], pb = sh.UW[min(16 + r16, kc) * n + i];
+            const double pref = dl_p / r_p;                                      // source/model.cpp:132 (IEEE division) for the accepted proposal only, issued behind the LDS reads: its dozen dependent operations run under their latency
             // the pivot's G column / row elements from set gs: this group's 16 loads are done once at most the 32 younger ones are pending
             int ulo, uhi, wlo, whi;
-            if (AS::enabled && as_inflight(as)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (nothing is in flight then: the publish drained)
-            else asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(32)" ::: "memory");                   // (while a window is in flight nothing is outstanding at all: its publish drained)
             DQ_W6_PICK(gs * 8 + first);
             double uj = __hiloint2double(uhi, ulo), wj = __hiloint2double(whi, wlo);
             DQ_ST(STAMP(t1))

@@ -9,7 +9,7 @@ from dqmc_amd.abi import DqmcLib
 paths = sys.argv[1:2]
 nsw = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 the_lib = DqmcLib(paths[0], "dqmc_")
-m = dqmc_amd.HubbardModel(**dqmc_amd.CONFIGS["cfg3"])
+m = dqmc_amd.HubbardModel(**dqmc_amd.CONFIGS[os.environ.get("AB_CFG", "cfg3")])      # AB_CFG=cfg5: the N = 576 path
 e0 = m.engine(the_lib); e0.set_fields(m.random_fields(3)); e0.init()
 rng = np.random.default_rng(0)
 for _ in range(3):
