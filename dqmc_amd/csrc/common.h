@@ -191,7 +191,8 @@ constexpr unsigned SLICE_EPOCH_LIMIT = 1u << 24;
 constexpr unsigned SLICE_SOLO_BIT = 1u << 30, SLICE_FINAL_BIT = 1u << 31;
 __host__ __device__ inline unsigned slice_tag(unsigned epoch, unsigned window) { return (epoch << 8) | window; }
 // one slice = reset + windows x (scan kernel, flush kernel)
-int launch_update_slice(const UpdateDesc& d, int l, int acc_slot, int n_chains, hipStream_t s);
+// *gt_kept (optional): 1 when the path taken keeps d.GT equal to G^T, 0 when it leaves GT behind (n > 256 on the scan / flush kernel pairs)
+int launch_update_slice(const UpdateDesc& d, int l, int acc_slot, int n_chains, hipStream_t s, int* gt_kept = nullptr);
 // sub-matrix variant of the persistent single-launch slice kernel (update_sm.hip)
 int launch_update_slice_sm(const UpdateDesc& d, int l, int acc_slot, int n_chains, hipStream_t s);
 int slice_flush_workgroups(int n);        // flush workgroups per chain of the persistent slice kernels

@@ -504,7 +504,9 @@ struct Engine {
             // every launch of a persistent slice kernel gets its own number: the hand-off words carry it, so none has to be re-armed
             if (++slice_epoch >= SLICE_EPOCH_LIMIT) { DQ_HIP(hipMemsetAsync(slice_sync, 0, (size_t)C * SLICE_SYNC_BYTES, s)); slice_epoch = 1; }
         }
-        DQ_TRY(launch_update_slice(udesc(), l, l, C, s));
+        int gt_kept = 1;
+        DQ_TRY(launch_update_slice(udesc(), l, l, C, s, &gt_kept));
+        if (!gt_kept) gt_valid = false;                               // n > 256 on the kernel pairs: the next persistent launch transposes first
         if (profiling) DQ_HIP(hipEventRecord(e1, s));
         return 0;
     }

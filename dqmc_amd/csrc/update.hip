@@ -947,8 +947,9 @@ int update_init_device() {
     return 0;
 }
 
-int launch_update_slice(const UpdateDesc& d, int l, int acc_slot, int n_chains, hipStream_t s) {
+int launch_update_slice(const UpdateDesc& d, int l, int acc_slot, int n_chains, hipStream_t s, int* gt_kept) {
     const int n = d.n;
+    if (gt_kept) *gt_kept = 1;
     if (n > 1024) { set_error("local update kernel supports n_sites <= 1024"); return -1; }
     const int kd = pick_kd(n);
     const int threads = ((n + 63) / 64) * 64;
@@ -998,6 +999,7 @@ int launch_update_slice(const UpdateDesc& d, int l, int acc_slot, int n_chains, 
             hipLaunchKernelGGL(scan_kernel<256>, dim3(1, n_chains), dim3(threads), lds, s, d, l, acc_slot, w == 0 ? 1 : 0, kd);
             hipLaunchKernelGGL(flush_kernel<true>, dim3(tiles * tiles, n_chains), dim3(256), 0, s, d, tiles, kd);
         } else {
+            if (gt_kept) *gt_kept = 0;                                                 // flush_kernel<false> updates G only
             hipLaunchKernelGGL(scan_kernel<1024>, dim3(1, n_chains), dim3(threads), lds, s, d, l, acc_slot, w == 0 ? 1 : 0, kd);
             hipLaunchKernelGGL(flush_kernel<false>, dim3(tiles * tiles, n_chains), dim3(256), 0, s, d, tiles, kd);
         }
