@@ -22,7 +22,8 @@
 //     fire-and-forget.
 // Thread map (512 threads = 8 waves, two per SIMD): col = t & 255, half = t >> 8.
 //   half h: the 16-row blocks h, h + 2 in LDS and 4 + h, 6 + h, ..., 14 + h in registers (interleaved: see CO_ACT)
-// The half that owns row k ("active" half of step k) updates the partial column norms vn1 / vn2, which live in LDS.
+// The partial column norms vn1 / vn2 live in LDS and are down-dated by half 0 at every step (the half with less FMA work: its row
+// blocks die one block earlier); the half that owns row k ("active" half of step k) only stores R0(k, :).
 // Register file by hand.  192 of the 256 VGPRs of a thread hold matrix rows for the whole kernel, and the register
 // allocator cannot be talked into that: as C arrays or vector types the rows were spilled and reloaded around every
 // asm block (2755 .. 10139 spills, 2.7 ms per factorisation).  So the matrix registers are taken out of its hands:
@@ -285,8 +286,8 @@ __global__ __launch_bounds__(CO_T) __attribute__((amdgpu_num_vgpr(32))) void qrc
             /* ---- row k is final: R0(k, c); partial column norms (dlaqp2 down-date), next pivot candidates.  BEFORE the update of the   \
                rows below: the latency-bound norm arithmetic of this half overlaps with the FMA blocks of the other half's wave on the same SIMD ---- */                  \
             bool need = false;                                                                                                        \
-            if (half == act) {                                                                                                        \
-                const double rk = (col == p) ? beta : ak - wc;                                                                        \
+            const double rk = (col == p) ? beta : ak - wc;                                                                            \
+            if (half == act) {                             /* the owner of row k stores R0(k, c) */                                   \
                 if (upd) {                                                                                                            \
                     if ((JB) < 4) sh.alds[k * CO_N + col] = rk;                                                                       \
                     else {                                                                                                            \
@@ -296,6 +297,8 @@ __global__ __launch_bounds__(CO_T) __attribute__((amdgpu_num_vgpr(32))) void qrc
                         else if ((((JB) - 4) >> 1) == 4) { CO_RSET_4(q, rk) } else { CO_RSET_5(q, rk) }                                  \
                     }                                                                                                                 \
                 }                                                                                                                     \
+            }                                                                                                                         \
+            if (half == 0) {                               /* norm down-dates and pivot candidates: ALWAYS half 0 (every thread has a_kc and w_c); half 1's row blocks die one block later, it is the slower half in both FMA phases (stamps: dots 1 300 against 960 clk per step, update 1 850 against 1 550) */ \
                 double vn1 = sh.vn[col];                                                                                              \
                 if (live && vn1 != 0.0) {                                                                                             \
                     double temp = fabs(rk) / vn1; temp = fmax(0.0, 1.0 - temp * temp);                                                \
