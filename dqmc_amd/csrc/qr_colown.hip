@@ -298,7 +298,7 @@ __global__ __launch_bounds__(CO_T) __attribute__((amdgpu_num_vgpr(32))) void qrc
                     }                                                                                                                 \
                 }                                                                                                                     \
             }                                                                                                                         \
-            if (half == 0) {                               /* norm down-dates and pivot candidates: ALWAYS half 0 (every thread has a_kc and w_c); half 1's row blocks die one block later, it is the slower half in both FMA phases (stamps: dots 1 300 against 960 clk per step, update 1 850 against 1 550) */ \
+            if (half == 0) {                               /* norm down-dates and pivot candidates: ALWAYS half 0 (every thread has a_kc and w_c); half 1 is the slower half in both FMA phases (stamps: dots 1 300 against 960 clk per step, update 1 850 against 1 550).  Measured: on the active half (alternating) 1 022 us per to_ldr, on half 0 957, split two waves + two waves 997 */ \
                 double vn1 = sh.vn[col];                                                                                              \
                 if (live && vn1 != 0.0) {                                                                                             \
                     double temp = fabs(rk) / vn1; temp = fmax(0.0, 1.0 - temp * temp);                                                \
