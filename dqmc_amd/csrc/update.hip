@@ -221,9 +221,18 @@ template <bool COH>
 __device__ __forceinline__ void walk6_load_group(const double* __restrict__ G, const double* __restrict__ GT, const ScanShared& sh, int g, int gs, int n, int j, bool live) {
     const unsigned jj8 = (unsigned)(live ? j : n - 1) * 8u, n8 = (unsigned)n * 8u;
     const int ig = sh.site[min(g * 8 + (int)(threadIdx.x & 7), n - 1)];       // lane q (mod 8): site of proposal 8 g + q, clamped: loads stay unconditional
+    // lane q of every 16-lane row holds the site of proposal q: its column offset reaches all lanes as the DPP operand of the add that
+    // forms the address -- one instruction per proposal (v_readlane + scalar multiply + add with their VALU -> SALU -> VALU hops before)
+    const unsigned igs = (unsigned)ig * n8;
     unsigned off8[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) off8[q] = jj8 + (unsigned)__builtin_amdgcn_readlane(ig, q) * n8;
+    // (one statement: the s_nop covers the VALU write of igs -> DPP read hazard, which the compiler does not see inside inline asm)
+    asm("s_nop 1\n\t"
+        "v_add_u32_dpp %0, %8, %9 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\tv_add_u32_dpp %1, %8, %9 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_u32_dpp %2, %8, %9 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\tv_add_u32_dpp %3, %8, %9 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_u32_dpp %4, %8, %9 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\tv_add_u32_dpp %5, %8, %9 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_u32_dpp %6, %8, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\tv_add_u32_dpp %7, %8, %9 row_newbcast:7 row_mask:0xf bank_mask:0xf"
+        : "=&v"(off8[0]), "=&v"(off8[1]), "=&v"(off8[2]), "=&v"(off8[3]), "=&v"(off8[4]), "=&v"(off8[5]), "=&v"(off8[6]), "=&v"(off8[7])
+        : "v"(igs), "v"(jj8));
     if (gs == 0) { if (COH) { DQ_W6_LOADSET_0_COH } else { DQ_W6_LOADSET_0_PLAIN } }
     else if (gs == 1) { if (COH) { DQ_W6_LOADSET_1_COH } else { DQ_W6_LOADSET_1_PLAIN } }
     else { if (COH) { DQ_W6_LOADSET_2_COH } else { DQ_W6_LOADSET_2_PLAIN } }
