@@ -215,8 +215,8 @@ __device__ __forceinline__ bool scan_group(const double (&pc)[SCAN_PF], const do
 #pragma clang diagnostic ignored "-Winline-asm"
 
 // issues the loads of the 8 proposals of group g into prefetch set gs = g % 3 (AGPRs; nothing waits here).  Addresses: constant
-// scalar bases G / GT + a 32-bit lane offset (j + n * site) * 8, the column part n * site * 8 formed on the scalar ALU from one
-// lane-distributed LDS read of the group's sites (three instructions per proposal in front of its two loads).
+// scalar bases G / GT + a 32-bit lane offset (j + n * site) * 8, the column part n * site * 8 taken from one lane-distributed LDS
+// read of the group's sites by a DPP broadcast inside the add (one instruction per proposal in front of its two loads).
 template <bool COH>
 __device__ __forceinline__ void walk6_load_group(const double* __restrict__ G, const double* __restrict__ GT, const ScanShared& sh, int g, int gs, int n, int j, bool live) {
     const unsigned jj8 = (unsigned)(live ? j : n - 1) * 8u, n8 = (unsigned)n * 8u;
