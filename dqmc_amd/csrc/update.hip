@@ -708,7 +708,10 @@ __device__ __forceinline__ void flush_tiles_lds(double* __restrict__ G, double* 
 // checked in, every later hand-off completes in bounded time (resident workgroups always make progress), so the spin bounds
 // below are a net for device faults only.
 // the solo fall-back's flush as a real function call: inlined, its registers join the walk's allocation problem and the hot loop of
-// the walk ends up with tuple copies and scratch spills (seen in the ISA); a call happens between windows, where almost nothing is live
+// the walk ends up with tuple copies and scratch spills (seen in the ISA); a call happens between windows, where almost nothing is live.
+// A called function is NOT bound by the kernel's register budget (its ISA uses v128 and up freely) and the compiler saves nothing of the
+// hand-managed file around the call: every call site sits where that file is dead -- all pending pairs have just been applied (k = 0
+// afterwards) and the prefetch sets are reloaded from the new G right after it.
 __device__ __attribute__((noinline)) void solo_flush(double* G, double* GT, const double2* UW, int n, int k) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int tiles16 = (n + 15) / 16, n_st = tiles16 * tiles16;
