@@ -426,8 +426,7 @@ def test_set_G_and_reinit_are_consistent(hip, orc):
 
 def test_alternative_kernel_paths_in_subprocess(hip):
     """Every env-switch kernel variant that is still shipped (the sub-matrix walk, the scan / flush kernel pairs, the solo slice
-    kernel, dgetrf + dgetrs instead of Gauss-Jordan, the single-wave Gauss-Jordan panel, the streaming QRCP, the unblocked form-Q,
-    the block-by-block initialisation)
+    kernel, dgetrf + dgetrs instead of Gauss-Jordan, the streaming QRCP, the block-by-block initialisation)
     runs the golden fixtures in a fresh process (the switches are read once per process) and is compared ELEMENT-WISE with the
     independent numpy evaluation stored there: G(0,0), log det, G and the HS fields after a full sweep at cfg 2 and cfg 3, and the
     same for every chain of a 4-chain batched engine at cfg 2."""
