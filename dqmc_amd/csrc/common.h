@@ -167,6 +167,8 @@ struct UpdateDesc {
     void* slice_sync = nullptr;               // per chain SLICE_SYNC_BYTES: hand-off words of the persistent slice kernels (null -> multi-kernel path)
     unsigned slice_epoch = 0;                 // launch number of the persistent slice kernel on this engine (1, 2, ...): every hand-off word carries it
     int slice_absent_tile = -1;               // debug (DQMC_DEBUG_SLICE_ABSENT): this flush workgroup leaves at once, as if it had never become resident
+    int slice_absent_l = -1;                  // debug (DQMC_DEBUG_SLICE_ABSENT=<tile>:<slice>): only in the launch of that time slice (-1: in every launch)
+    int slice_late_tile = -1, slice_late_us = 0;   // debug (DQMC_DEBUG_SLICE_LATE=<tile>:<us>): this flush workgroup sleeps that long before it checks in
     int* info = nullptr;                      // |= 4 when a hand-off of the persistent slice kernel timed out
     int* acc_out; long acc_stride;            // per chain per slice accepted counts [chain][2*nt] (+ offset chosen by caller)
     int n, nt;

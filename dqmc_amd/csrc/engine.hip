@@ -257,6 +257,8 @@ struct Engine {
     bool persistent = false;                                     // holds a CU reservation for the single-launch slice kernel (slice_reserve)
     bool handoff_failed = false;                                 // a hand-off of a persistent kernel timed out once: this engine stays on the kernel pairs from then on
     unsigned slice_epoch = 0;                                    // launches of the persistent slice kernel so far: the tag of its hand-off words (SliceSync, common.h)
+    int slice_absent_l = -1;                                     // ...=<tile>:<slice>: only in the launch of that time slice
+    int slice_late_tile = -1, slice_late_us = 0;                 // DQMC_DEBUG_SLICE_LATE=<tile>:<us>: that flush workgroup checks in only after <us> microseconds (test of a LATE arrival)
     int slice_absent_tile = -1;                                  // DQMC_DEBUG_SLICE_ABSENT=<tile>, read when the engine is created: that flush workgroup never checks in (test of the solo fall-back)
     int* acc = nullptr;                                          // [C][nt]
     double* err = nullptr;                                       // [C][n_stack]
@@ -301,7 +303,8 @@ struct Engine {
         g_host.assign(g, g + C); gamma_host.assign(gamma, gamma + 4); eta_host.assign(eta, eta + 4);
         DQ_TRY(ctx.init(n, C, device)); s = ctx.stream;
         persistent = slice_reserve(device, n, C);
-        if (const char* a = getenv("DQMC_DEBUG_SLICE_ABSENT")) slice_absent_tile = atoi(a);
+        if (const char* a = getenv("DQMC_DEBUG_SLICE_ABSENT")) { slice_absent_tile = atoi(a); if (const char* c = strchr(a, ':')) slice_absent_l = atoi(c + 1); }
+        if (const char* a = getenv("DQMC_DEBUG_SLICE_LATE")) { slice_late_tile = atoi(a); if (const char* c = strchr(a, ':')) slice_late_us = atoi(c + 1); }
         DQ_TRY(dalloc(&expK, C * nn)); DQ_TRY(dalloc(&invexpK, C * nn));
         DQ_TRY(dalloc(&fields, (size_t)C * nt * n)); DQ_TRY(dalloc(&expv, (size_t)C * nt * n)); DQ_TRY(dalloc(&invexpv, (size_t)C * nt * n));
         DQ_TRY(dalloc(&tabs, C)); DQ_TRY(dalloc(&tab8, (size_t)C * 8));
@@ -490,7 +493,7 @@ struct Engine {
     UpdateDesc udesc() const {
         UpdateDesc d; d.G = mG(); d.fields = fields; d.f_stride = (long)nt * n; d.expv = expv; d.invexpv = invexpv; d.v_stride = (long)nt * n;
         d.tabs = tabs; d.perm = rs_perm; d.kprop = rs_k; d.u = rs_u; d.rs_stride = (long)nt * n; d.Upanel = Upanel; d.Wpanel = Wpanel; d.Cpanel = Cpanel;
-        d.panel_stride = (long)UPDATE_KD * n; d.state = state; d.state_stride = 4; d.prep = prep; d.prep_stride = 4L * n; d.slice_sync = (persistent && !handoff_failed) ? slice_sync : nullptr; d.slice_epoch = slice_epoch; d.slice_absent_tile = slice_absent_tile; d.GT = Mat{GT, nn}; d.gt_valid = gt_valid ? 1 : 0; d.info = ctx.info(); d.acc_out = acc; d.acc_stride = nt; d.n = n; d.nt = nt;
+        d.panel_stride = (long)UPDATE_KD * n; d.state = state; d.state_stride = 4; d.prep = prep; d.prep_stride = 4L * n; d.slice_sync = (persistent && !handoff_failed) ? slice_sync : nullptr; d.slice_epoch = slice_epoch; d.slice_absent_tile = slice_absent_tile; d.slice_absent_l = slice_absent_l; d.slice_late_tile = slice_late_tile; d.slice_late_us = slice_late_us; d.GT = Mat{GT, nn}; d.gt_valid = gt_valid ? 1 : 0; d.info = ctx.info(); d.acc_out = acc; d.acc_stride = nt; d.n = n; d.nt = nt;
         return d;
     }
     int local_update(int l) {
@@ -636,10 +639,22 @@ struct Engine {
             for (size_t k = 0; k < ev_used; ++k) { float ms = 0.f; DQ_HIP(hipEventElapsedTime(&ms, ev_pairs[k].first, ev_pairs[k].second)); upd_ms += ms; }
             upd_launches += (long long)ev_used; ev_used = 0;
         }
-        int h_info = 0;
-        DQ_HIP(hipMemcpy(&h_info, ctx.info(), sizeof(int), hipMemcpyDeviceToHost));
+        int h_info2[2] = {0, 0};
+        DQ_HIP(hipMemcpy(h_info2, ctx.info(), 2 * sizeof(int), hipMemcpyDeviceToHost));
+        const int h_info = h_info2[0];
         if (h_info & 4) { handoff_failed = true; gt_valid = false; set_error("persistent slice kernel: a workgroup that had checked in stopped answering (device fault or pre-emption beyond the spin bound); the chain state is undefined -- set the fields again and call dqmc_init; this engine uses the scan / flush kernel pairs from now on"); (void)hipMemset(ctx.info(), 0, sizeof(int)); (void)hipMemset(slice_sync, 0, (size_t)C * SLICE_SYNC_BYTES); slice_epoch = 0; return DQMC_ENUMERIC; }
-        if (h_info & 8) { handoff_failed = true; gt_valid = false; set_error("persistent sub-matrix slice kernel: its workgroups did not all become resident (device shared with other work?); the slice was left untouched before anything was modified -- this engine uses the scan / flush kernel pairs from now on, re-run the sweep"); (void)hipMemset(ctx.info(), 0, sizeof(int)); return DQMC_ENUMERIC; }
+        if (h_info & 8) {
+            // n > 256: the census of slice_sm_kernel failed at slice info[1] - 1.  That launch and (device-side latch, update_sm.hip) every later
+            // slice_sm_kernel launch enqueued behind it left their slices untouched; the wraps and stabilisations of the calls in flight ran.
+            handoff_failed = true; gt_valid = false;
+            char msg[640];
+            snprintf(msg, sizeof msg, "persistent sub-matrix slice kernel: its workgroups did not all become resident at time slice %d (device shared with other "
+                     "work?).  That slice and every later slice of the call(s) in flight proposed NOTHING (fields unchanged there, acceptance counts 0, their part of "
+                     "the random stream is spent); wraps and stabilisations ran, so fields, G and the stack are consistent with each other, but the sweep is not the "
+                     "one the stream describes from that slice on.  This engine uses the scan / flush kernel pairs from now on: restore the fields of the last "
+                     "completed sweep and call dqmc_init, or keep the state as a valid (shortened) sweep", h_info2[1] - 1);
+            set_error(msg); (void)hipMemset(ctx.info(), 0, 2 * sizeof(int)); return DQMC_ENUMERIC;
+        }
         if (h_info & 2) { set_error("cooperative QRCP gave up waiting for a partner workgroup (not co-resident?)"); (void)hipMemset(ctx.info(), 0, sizeof(int)); return DQMC_ENUMERIC; }
         if (h_info) { set_error("LU factorisation hit a zero or NaN pivot"); (void)hipMemset(ctx.info(), 0, sizeof(int)); return DQMC_ENUMERIC; }
         return 0;

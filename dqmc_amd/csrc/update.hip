@@ -740,7 +740,11 @@ __global__ __launch_bounds__(256) DQ_WALK_REGS void slice_kernel(UpdateDesc d, S
     if (blockIdx.x > 0) {
         // ================= flush role: one 32x32 tile of G, one 16x16 sub-tile per wave =================
         const int tile = blockIdx.x - 1;
-        if (tile == d.slice_absent_tile) return;                      // debug: a workgroup that never becomes resident
+        if (tile == d.slice_absent_tile && (d.slice_absent_l < 0 || d.slice_absent_l == l)) return;                      // debug: a workgroup that never becomes resident
+        if (tile == d.slice_late_tile) {                              // debug: a workgroup that becomes resident LATE (after the walk's census has given up)
+            const unsigned long long t0 = wall_clock64();             // 100 MHz
+            while (wall_clock64() - t0 < 100ull * (unsigned long long)d.slice_late_us) __builtin_amdgcn_s_sleep(64);
+        }
         const int a0 = (tile % tiles_per_dim) * 32 + (wave & 1) * 16;
         const int b0 = (tile / tiles_per_dim) * 32 + (wave >> 1) * 16;
         if (t == 0) __hip_atomic_store(&sy->arrive[tile], slice_tag(epoch, 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // census: resident
@@ -752,7 +756,16 @@ __global__ __launch_bounds__(256) DQ_WALK_REGS void slice_kernel(UpdateDesc d, S
                 unsigned long long word = 0; unsigned spins = 0; bool give_up = false;
                 for (;;) {
                     word = __hip_atomic_load(&sy->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if ((unsigned)(word >> 32) == slice_tag(epoch, win)) break;
+                    const unsigned tag = (unsigned)(word >> 32);
+                    if (tag == slice_tag(epoch, win)) break;
+                    if ((tag >> 8) == (slice_tag(epoch, 0) >> 8)) {
+                        // a word of THIS launch for another window.  Solo: the walk gave up on the census before this workgroup checked in
+                        // and has been applying its windows itself ever since (every word it publishes carries the bit) -- a workgroup that
+                        // becomes resident late sees window 2, 3, ... and never window 1: it leaves, G is not its to touch.  Anything else
+                        // (a later window without the solo bit) cannot happen while this workgroup's arrival is outstanding: fail at once.
+                        if ((unsigned)word & SLICE_SOLO_BIT) break;
+                        if ((tag & 0xffu) > win) { give_up = true; break; }
+                    }
                     if (++spins > SLICE_SPIN_LIMIT) { give_up = true; break; }
                     __builtin_amdgcn_s_sleep(1);
                 }

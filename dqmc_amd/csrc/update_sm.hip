@@ -389,7 +389,7 @@ __global__ __launch_bounds__(256) void slice_sm_kernel(UpdateDesc d, SliceSync* 
 
     if (blockIdx.x > 0) {
         // ================= flush role: 32x32 tiles of G, one 16x16 sub-tile per wave =================
-        if ((int)blockIdx.x - 1 == d.slice_absent_tile) return;       // debug: a workgroup that never becomes resident
+        if ((int)blockIdx.x - 1 == d.slice_absent_tile && (d.slice_absent_l < 0 || d.slice_absent_l == l)) return;       // debug: a workgroup that never becomes resident
         if (t == 0) __hip_atomic_store(&sy->arrive[blockIdx.x - 1], slice_tag(epoch, 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // census: resident
         // one wave polls the window word, the others take it from LDS (polling cost: guide, Guideline 16 Pitfall 9)
         unsigned long long* bcast = reinterpret_cast<unsigned long long*>(smem);
@@ -448,9 +448,15 @@ __global__ __launch_bounds__(256) void slice_sm_kernel(UpdateDesc d, SliceSync* 
         // have not after a bounded wait, the walk publishes the abort flag and leaves: the slice stays exactly as it was (fields, exp(V)
         // tables and G untouched), info |= 8 tells the host, the engine takes the kernel pairs from then on.  Once all have checked in,
         // every later hand-off completes in bounded time (resident workgroups always make progress).
+        // latch: once a slice of this engine has been abandoned (info & 8), no later launch of the same sweep may update either -- the sweep
+        // would otherwise contain a slice that proposed nothing between slices that did, a trajectory that belongs to no Markov chain the
+        // caller asked for.  Later launches publish the abort word at once (no census wait) and leave; the host reports the first
+        // abandoned slice (info[1]) and what state the engine is in (engine.hip: sync_and_check).
+        const bool latched = info && (__hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 8);
         if (wave == 0) {
             unsigned spins = 0; bool all_in = false;
             for (;;) {
+                if (latched) break;
                 bool in = true;
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
@@ -465,7 +471,8 @@ __global__ __launch_bounds__(256) void slice_sm_kernel(UpdateDesc d, SliceSync* 
             if (!all_in && lane == 0) {
                 __hip_atomic_store(&sy->seq, ((unsigned long long)slice_tag(epoch, 1) << 32) | SLICE_SOLO_BIT | SLICE_FINAL_BIT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_fetch_add(&sy->solo_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (info) atomicOr(info, 8);
+                if (info) { atomicOr(info, 8); atomicCAS(info + 1, 0, l + 1); }      // info[1]: first abandoned slice + 1
+                d.acc_out[(long)chain * d.acc_stride + acc_slot] = 0;               // nothing was proposed in this slice
             }
         }
         __syncthreads();                                              // (orders the prologue's LDS writes as well)

@@ -16,9 +16,18 @@ import scipy.linalg as sla
 from dqmc_amd.model import PROPOSAL, HubbardModel
 
 
+_QR = None          # None = dgeqp3 (the reference's); oracle/panel_qr.py variants are plugged in by scripts/eval_panel_qr.py
+
+
+def set_qr(fn):
+    """Replace the pivoted QR behind to_ldr by fn(M) -> (Q, R0, P) (evaluation of panel-pivoted variants); None restores dgeqp3."""
+    global _QR
+    _QR = fn
+
+
 def to_ldr(M):
     """stablelinalg::to_LDR, source/stablelinalg.cpp:35-55."""
-    Q, R0, P = sla.qr(M, pivoting=True)
+    Q, R0, P = sla.qr(M, pivoting=True) if _QR is None else _QR(M)
     d = np.abs(np.diag(R0))
     Rn = R0 / d[:, None]
     R = np.empty_like(Rn)

@@ -1,0 +1,159 @@
+"""Panel-pivoted (blocked) QR variants evaluated against dgeqp3 -- TEST INFRASTRUCTURE ONLY.
+
+`stablelinalg::to_LDR` (source/stablelinalg.cpp:35-55) calls `arma::qr(Q, R, P, M, "vector")` = LAPACK dgeqp3: one
+global pivot decision per column, i.e. N dependent chip-wide reductions.  The functions here restate factorisations
+that take ONE global decision per PANEL of b columns and are used (a) by `scripts/eval_panel_qr.py` to decide whether a
+panel-pivoted to_LDR holds the 1e-10 parity bar on the DQMC matrices, (b) as the numpy statement of the algorithm the
+HIP kernels in dqmc_amd/csrc/qr_panel.hip implement (`qr_sketch`), for the unit tests.
+
+Every function returns (Q, R0, P) with M[:, P] = Q @ R0 like scipy.linalg.qr(M, pivoting=True).
+
+* qr_tournament  -- communication-avoiding RRQR (Demmel, Grigori, Gu, Xiang): the b pivots of a panel are the winners of
+                    a binary play-off of local dgeqp3 runs on groups of 2b full-height columns.
+* qr_sketch      -- randomised panel pivoting (Duersch & Gu; Martinsson et al., HQRRP): the b pivots of a panel are the
+                    first b pivots of dgeqp3 on the (b + p) x n_c sketch  Y = Omega . A_trailing  with a FIXED Gaussian
+                    Omega (deterministic), the sketch re-formed from the updated trailing matrix for every panel (the
+                    down-dated sketch of HQRRP loses the small columns of a graded DQMC matrix to cancellation).
+* qr_normpanel   -- the b columns of largest current norm, exact dgeqp3 inside the panel (control: no view of the
+                    dependencies between candidates and the rest).
+"""
+from __future__ import annotations
+
+import numpy as np
+import scipy.linalg as sla
+
+
+def _finish(A, k, perm, Qs):
+    """Assemble (Q, R0, P) from the in-place reduced matrix."""
+    n = A.shape[0]
+    Q = np.eye(n)
+    for (k0, Qp) in reversed(Qs):
+        Q[k0:, k0:] = Qp @ Q[k0:, k0:]
+    return Q, np.triu(A), np.array(perm)
+
+
+def _apply_panel(A, k, b, perm, cols, Qs, local_pivot):
+    """Move trailing columns `cols` (indices relative to k, in pivot order) to the front of the trailing matrix, factor
+    the panel by Householder QR (exact dgeqp3 inside the panel when local_pivot) and update the rest."""
+    n = A.shape[0]
+    nc = n - k
+    rest = [c for c in range(nc) if c not in set(cols)]
+    order = list(cols) + rest
+    A[:, k:] = A[:, k + np.array(order)]
+    perm[k:] = [perm[k + c] for c in order]
+    b = len(cols)
+    if local_pivot:
+        Qp, Rp, pp = sla.qr(A[k:, k:k + b], pivoting=True)
+        A[:k, k:k + b] = A[:k, k + pp]
+        perm[k:k + b] = [perm[k + c] for c in pp]
+    else:
+        Qp, Rp = sla.qr(A[k:, k:k + b])
+    A[k:, k:k + b] = Rp
+    A[k:, k + b:] = Qp.T @ A[k:, k + b:]
+    Qs.append((k, Qp))
+
+
+def _qr_sign(Q, R0):
+    return Q, R0
+
+
+def qr_tournament(M, b=32, local_pivot=False):
+    A = np.array(M, dtype=np.float64, copy=True)
+    n = A.shape[0]
+    perm = list(range(n)); Qs = []
+    k = 0
+    while k < n:
+        nc = n - k
+        bb = min(b, nc)
+        cand = list(range(nc))
+        while len(cand) > bb:
+            nxt = []
+            for g in range(0, len(cand), 2 * bb):
+                grp = cand[g:g + 2 * bb]
+                if len(grp) <= bb:
+                    nxt += grp
+                    continue
+                _, _, pg = sla.qr(A[k:, k + np.array(grp)], pivoting=True, mode="economic")
+                nxt += [grp[j] for j in pg[:bb]]
+            cand = nxt
+        # a final ordering of the winners among themselves
+        if len(cand) > 1:
+            _, _, pg = sla.qr(A[k:, k + np.array(cand)], pivoting=True, mode="economic")
+            cand = [cand[j] for j in pg]
+        _apply_panel(A, k, bb, perm, cand, Qs, local_pivot)
+        k += bb
+    return _finish(A, k, perm, Qs)
+
+
+_OMEGA = {}
+
+
+def omega(rows, n, seed=20240229):
+    """The fixed sketching matrix: rows x n i.i.d. standard normal from a seeded generator (the HIP library carries the same
+    numbers: a counter-based generator evaluated on the device would do as well, the values only need to be fixed)."""
+    key = (rows, n, seed)
+    if key not in _OMEGA:
+        _OMEGA[key] = np.random.default_rng(seed).standard_normal((rows, n))
+    return _OMEGA[key]
+
+
+def omega_sign(rows, n):
+    """Rademacher sketching matrix from an integer hash of (row, column): Omega[i, r] = +-1.  This is the matrix the HIP
+    kernels generate in registers (dqmc_amd/csrc/qr_panel.hip: `sketch_sign`), so the products Omega . A are sums of +-a_rc."""
+    key = (rows, n, "sign")
+    if key not in _OMEGA:
+        i = np.arange(rows, dtype=np.uint64)[:, None]; r = np.arange(n, dtype=np.uint64)[None, :]
+        h = (i * np.uint64(0x9E3779B1) + r * np.uint64(0x85EBCA77) + np.uint64(0xC2B2AE3D)) & np.uint64(0xFFFFFFFF)
+        h ^= h >> np.uint64(15); h = (h * np.uint64(0x2C1B3C6D)) & np.uint64(0xFFFFFFFF)
+        h ^= h >> np.uint64(12); h = (h * np.uint64(0x297A2D39)) & np.uint64(0xFFFFFFFF)
+        h ^= h >> np.uint64(15)
+        _OMEGA[key] = np.where((h & np.uint64(1)) == 1, -1.0, 1.0)
+    return _OMEGA[key]
+
+
+def qr_sketch(M, b=32, p=8, local_pivot=True, sign=False):
+    A = np.array(M, dtype=np.float64, copy=True)
+    n = A.shape[0]
+    perm = list(range(n)); Qs = []
+    k = 0
+    while k < n:
+        nc = n - k
+        bb = min(b, nc)
+        if nc <= bb:
+            cand = list(range(nc))
+            if not local_pivot and nc > 1:
+                _, _, pg = sla.qr(A[k:, k:], pivoting=True, mode="economic")
+                cand = list(pg)
+        else:
+            Om = (omega_sign(b + p, n) if sign else omega(b + p, n))[:, k:]
+            Y = Om @ A[k:, k:]
+            _, _, pg = sla.qr(Y, pivoting=True, mode="economic")
+            cand = list(pg[:bb])
+        _apply_panel(A, k, bb, perm, cand, Qs, local_pivot)
+        k += bb
+    return _finish(A, k, perm, Qs)
+
+
+def qr_normpanel(M, b=32):
+    A = np.array(M, dtype=np.float64, copy=True)
+    n = A.shape[0]
+    perm = list(range(n)); Qs = []
+    k = 0
+    while k < n:
+        nc = n - k
+        bb = min(b, nc)
+        nrm = np.linalg.norm(A[k:, k:], axis=0)
+        cand = list(np.argsort(-nrm, kind="stable")[:bb])
+        _apply_panel(A, k, bb, perm, cand, Qs, True)
+        k += bb
+    return _finish(A, k, perm, Qs)
+
+
+def quality(R0):
+    """(max |r_ij| / |r_ii| over j > i, max d_j / d_i over j > i): both are <= 1 for dgeqp3."""
+    d = np.abs(np.diag(R0))
+    Rn = np.abs(np.triu(R0, 1)) / d[:, None]
+    up = float(Rn.max()) if Rn.size else 0.0
+    suf = np.maximum.accumulate(d[::-1])[::-1]
+    grade = float(np.max(suf[1:] / d[:-1])) if len(d) > 1 else 0.0
+    return up, grade

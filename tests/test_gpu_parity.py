@@ -722,6 +722,33 @@ def test_persistent_slice_kernel_survives_a_workgroup_that_never_becomes_residen
     e.close()
 
 
+@pytest.mark.parametrize("where", ["window_end", "inside_the_walk"])
+def test_persistent_slice_kernel_survives_a_workgroup_that_becomes_resident_late(hip, orc, monkeypatch, where):
+    """What hardware can actually do to the census: a flush workgroup that gets its CU AFTER the walk has given up on it.  With
+    DQMC_DEBUG_SLICE_LATE=<tile>:<us> the workgroup sleeps 3 ms before it checks in -- far beyond the census wait (~0.1-0.2 ms) --
+    so the walk has gone solo and published window 2, 3, ... by the time the workgroup polls for window 1.  It must recognise a
+    word of its own launch with the solo bit, whatever the window, and leave at once: path 2, no error, the oracle's trajectory,
+    and a launch that lasts as long as the sleep, not the 2^22-poll spin bound (> 4 s per slice before round 4)."""
+    import time
+    m = HubbardModel(**CONFIGS["cfg2"]) if where == "window_end" else HubbardModel(L1=16, L2=16, U=8.0, beta=1.0, nt=10, n_stab=5)
+    rng = np.random.default_rng(79)
+    f0 = m.random_fields(7); sf, sb = m.random_stream(rng), m.random_stream(rng)
+    monkeypatch.setenv("DQMC_DEBUG_SLICE_LATE", "2:3000")          # read when the engine is created
+    e = m.engine(hip)
+    monkeypatch.delenv("DQMC_DEBUG_SLICE_LATE")
+    if e.slice_path() == 0:
+        pytest.skip("no CU reservation left for a persistent slice kernel (engines of other tests still alive)")
+    o = m.engine(orc)
+    o.set_fields(f0); o.init(); o.sweep_0_to_beta(*sf); o.sweep_beta_to_0(*sb)
+    e.set_fields(f0); e.init()
+    t0 = time.time(); e.sweep_0_to_beta(*sf); e.sweep_beta_to_0(*sb); G = e.get_G(); dt = time.time() - t0
+    assert e.slice_path() == 2, "the solo fall-back was not taken"
+    assert (e.get_fields() == o.get_fields()).all() and e.stats().n_accepted == o.stats().n_accepted
+    assert close(G, o.get_G())
+    assert dt < 2 * m.nt * (0.003 + 0.02) + 2.0, "a late flush workgroup held its launch for %.1f s" % dt
+    e.close()
+
+
 def test_persistent_submatrix_kernel_leaves_the_slice_untouched_when_the_grid_is_incomplete(hip, orc, monkeypatch):
     """n > 256: the sub-matrix slice kernel takes its census BEFORE the first window.  A flush workgroup that never checks in makes the
     walk leave with the slice exactly as it was (fields, tables and G untouched), the sweep reports DQMC_ENUMERIC, and the engine goes
@@ -745,6 +772,38 @@ def test_persistent_submatrix_kernel_leaves_the_slice_untouched_when_the_grid_is
     for x in (e, o):
         x.set_fields(f0); x.init(); x.sweep_0_to_beta(*sf); x.sweep_beta_to_0(*sb)
     assert (e.get_fields() == o.get_fields()).all() and close(e.get_G(), o.get_G())
+    e.close()
+
+
+def test_persistent_submatrix_kernel_abandons_the_rest_of_a_sweep_when_the_grid_is_incomplete(hip, orc, monkeypatch):
+    """n > 256, a SWEEP (asynchronously enqueued): the census fails in the launch of time slice 4 only (DQMC_DEBUG_SLICE_ABSENT=
+    <tile>:<slice>); every later launch finds its grid complete.  The device-side latch must keep those later slices from updating
+    -- a sweep with a hole is no sweep -- so the engine ends with: slices 0..3 updated exactly as the oracle's, slices 4.. untouched,
+    acceptance counts 0 there, the error naming slice 4, fields / G / stack consistent with each other (G equals a from-scratch
+    evaluation on the resulting fields), kernel pairs from then on."""
+    from dqmc_amd import DqmcError
+    m = HubbardModel(L1=18, L2=18, U=4.0, beta=2.0, nt=20, n_stab=10); rng = np.random.default_rng(80)
+    f0 = m.random_fields(8); sf = m.random_stream(rng)
+    monkeypatch.setenv("DQMC_DEBUG_SLICE_ABSENT", "3:4")
+    e = m.engine(hip)
+    monkeypatch.delenv("DQMC_DEBUG_SLICE_ABSENT")
+    if e.slice_path() == 0:
+        pytest.skip("no CU reservation left for a persistent slice kernel")
+    e.set_fields(f0); e.init()
+    with pytest.raises(DqmcError) as ei:
+        e.sweep_0_to_beta(*sf)
+    assert ei.value.code == -3 and "time slice 4" in str(ei.value), str(ei.value)
+    assert e.slice_path() == 0                                     # kernel pairs from now on
+    # the oracle walks slices 0..3 of the same stream and only wraps through the rest
+    o = m.engine(orc); o.set_fields(f0); o.init()
+    for l in range(4):
+        o.wrap_forward(l); o.local_update_slice(l, sf[0][l:l + 1], sf[1][l:l + 1], sf[2][l:l + 1])
+    fe = e.get_fields(); fo = o.get_fields()
+    assert (fe[:4] == fo[:4]).all() and (fe[4:] == f0[4:]).all()
+    assert not (fe[:4] == f0[:4]).all()                           # something was accepted before the hole
+    # G after the abandoned sweep is G(beta, beta) = G(0, 0) of the resulting fields
+    o2 = m.engine(orc); o2.set_fields(fe); o2.init()
+    assert close(e.get_G(), o2.get_G())
     e.close()
 
 
