@@ -5,7 +5,7 @@ ARCH  ?= gfx950
 CXX   ?= g++
 HIPFLAGS ?= -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-function
 CSRC := dqmc_amd/csrc
-OBJS := $(CSRC)/gemm.o $(CSRC)/elementwise.o $(CSRC)/checkerboard.o $(CSRC)/update.o $(CSRC)/update_sm.o $(CSRC)/qr.o $(CSRC)/qr_colown.o $(CSRC)/qr_coop.o $(CSRC)/lu.o $(CSRC)/lu_blocked.o $(CSRC)/lu_gj.o $(CSRC)/tri_solve.o $(CSRC)/engine.o $(CSRC)/replica.o
+OBJS := $(CSRC)/gemm.o $(CSRC)/elementwise.o $(CSRC)/checkerboard.o $(CSRC)/update.o $(CSRC)/update_sm.o $(CSRC)/qr.o $(CSRC)/qr_colown.o $(CSRC)/qr_coop.o $(CSRC)/qr_panel.o $(CSRC)/lu.o $(CSRC)/lu_blocked.o $(CSRC)/lu_gj.o $(CSRC)/tri_solve.o $(CSRC)/engine.o $(CSRC)/replica.o
 
 all: dqmc_amd/libdqmc_hip.so dqmc_amd/libdqmc_host.so dqmc_amd/dqmc_driver oracle
 

@@ -110,7 +110,12 @@ struct QrWork {
     unsigned long long* sync = nullptr; long sync_stride = 0;   // cooperative QRCP: granule records, >= qrcp_coop_sync_granules(n) per chain
     int* abort_words = nullptr;                                 // cooperative QRCP: one word per chain
     int* info = nullptr;                                        // |= 2 when a cooperative factorisation gave up waiting
+    double* pw = nullptr; long pw_stride = 0;                   // panel-pivoted QR (qr_panel.hip): sketch, clean reflector panel, T; >= qr_panel_work_doubles(n) per chain
+    int* pivpos = nullptr; long pivpos_stride = 0;              // panel-pivoted QR: pivot position of every column (-1 = live), n per chain
 };
+long qr_panel_work_doubles(int n);
+bool qr_panel_ok(int n, const QrWork& w);   // n a multiple of 16 in [16, 1024] and the workspace present
+int launch_qr_panel(Mat A, QrWork w, int n, int n_chains, hipStream_t s);   // qr_panel.hip: A -> reflectors / R0 in place, tau, jpvt (same format as the QRCP kernels)
 long qrcp_coop_sync_granules(int n);        // granules of cooperative-QRCP workspace per chain
 int qrcp_coop_workgroups(int n, int n_chains);
 int launch_to_ldr(Mat A, Mat L, Vec d, Mat R, QrWork w, int n, int n_chains, hipStream_t s);

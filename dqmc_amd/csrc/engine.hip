@@ -64,6 +64,8 @@ struct Ctx {
     unsigned long long* qsync = nullptr;       // cooperative QRCP records
     int* qabort = nullptr;                     // cooperative QRCP abort words: C
     double* tinv = nullptr;                    // Gauss-Jordan panel inverses: 2048 * C
+    double* qpw = nullptr;                     // panel-pivoted QR (qr_panel.hip): qr_panel_work_doubles(n) * C
+    int* qpivpos = nullptr;                    // ... and its pivot positions: n * C
     double* trinv = nullptr;                   // blocked triangular solve: inverses of the 16 x 16 diagonal blocks, 16 * (n + 16) * C
     bool use_tri = false;                      // R^-1 D by tri_solve.hip (n <= 640; the per-column substitution of lu.hip above that)
     bool use_gj = false;                       // n <= 256, few chains: solves go through lu_gj.hip (DQMC_LU_CLASSIC=1 keeps dgetrf + dgetrs)
@@ -90,6 +92,10 @@ struct Ctx {
         DQ_HIP(hipMalloc(&qabort, sizeof(int) * C));
         DQ_HIP(hipMalloc(&tinv, sizeof(double) * 2048 * C));
         DQ_HIP(hipMalloc(&trinv, sizeof(double) * 16 * (n + 16) * C));
+        if (n % 16 == 0 && n <= 1024) {
+            DQ_HIP(hipMalloc(&qpw, sizeof(double) * qr_panel_work_doubles(n) * C));
+            DQ_HIP(hipMalloc(&qpivpos, sizeof(int) * (size_t)n * C));
+        }
         use_tri = n <= 640;     // any number of chains (128 chains at cfg 3: 432.9 against 437.3 ms per step)
         // latency regime only: with many chains per launch the blocked LU + per-column substitution has the higher throughput
         // (128 chains, cfg 3: 458 ms per step against 483 ms with the single-wave panels)
@@ -108,6 +114,8 @@ struct Ctx {
         if (qabort) (void)hipFree(qabort);
         if (tinv) (void)hipFree(tinv);
         if (trinv) (void)hipFree(trinv);
+        if (qpw) (void)hipFree(qpw);
+        if (qpivpos) (void)hipFree(qpivpos);
         if (stream) (void)hipStreamDestroy(stream);
     }
 
@@ -122,6 +130,7 @@ struct Ctx {
         const bool keep = direct && out.jpvt != nullptr;
         QrWork w{V(7).p, (long)n, keep ? out.jpvt : jpvt(), (long)n};
         w.sync = qsync; w.sync_stride = qrcp_coop_sync_granules(n); w.abort_words = qabort; w.info = info();
+        w.pw = qpw; w.pw_stride = qr_panel_work_doubles(n); w.pivpos = qpivpos; w.pivpos_stride = n;
         if (out.tri) *out.tri = keep;
         return launch_to_ldr(A, out.L, out.d, out.R, w, n, C, stream);
     }

@@ -1,0 +1,394 @@
+// qr_panel.hip -- stablelinalg::to_LDR (source/stablelinalg.cpp:35-55) as a PANEL-pivoted blocked Householder QR.
+//
+// The reference factorises with dgeqp3 (arma::qr(Q, R, P, M, "vector")): one global pivot decision per COLUMN, i.e. n dependent
+// chip-wide steps (qr_colown.hip runs them on one CU in 3.2 us each, qr_coop.hip pays a cross-CU exchange for each).  to_LDR's
+// consumers only ever use the product L diag(d) R and the grading of d, so the pivot ORDER is free as long
+// as the factorisation stays rank-revealing.  Here one global decision is taken per panel of QP_B = 16 columns:
+//
+//   sketch     Y = Omega . A_trailing, Omega = QP_SR x m matrix of +-1 from an integer hash of the row index (fixed: the
+//              factorisation is deterministic), formed on the matrix cores by the update kernel from the tiles it has just
+//              updated -- the sketch is FRESH for every panel (a down-dated sketch loses the small columns of a graded DQMC
+//              matrix to cancellation);
+//   selection  the first 16 pivots of a column-pivoted Householder QR of the 32 x n_c sketch (one workgroup, lane <-> column, the
+//              column in registers, one barrier per step) are the panel's columns, in that order;
+//   panel      unpivoted Householder QR of the 16 selected full-height columns: lane <-> (column c = lane & 15, 16 rows), the
+//              pivot column reaches the other 15 lanes of its DPP row by row_newbcast (v_fmac_f64_dpp), so the 15 dot products
+//              and the 15 updates of a step are 16 DPP-FMAs each; ONE fused reduction per step yields the dots, the squared
+//              norm of the pivot column's tail and the entries v_c^T v_j of the compact-WY factor T;
+//   update     A <- (I - V T V^T)^T A on the trailing columns, 16 columns per workgroup, v_mfma_f64_16x16x4_f64.
+//
+// Randomised panel pivoting (Duersch & Gu 2017; Martinsson, Quintana-Orti, Heavner, van de Geijn 2017).  The numpy statement
+// of exactly this algorithm is oracle/panel_qr.py::qr_sketch(b = 16, p = 16, sign = True, local_pivot = False); its effect on
+// G (cfg 3 thermalised sweep 3e-11 absolute, cfg 3 / cfg 5 i.i.d. <= 3e-11 relative; tournament pivoting and Gaussian sketches
+// beside it) is in profiles/r04_eval_panel_qr_numpy.log.
+// Output format = the other QRCP kernels': reflectors and R0 in place in A WITHOUT column swaps, tau, jpvt (formq_* and
+// assemble_r_kernel of qr.hip finish L, d, R).
+#include "common.h"
+#include "wave.h"
+#include <utility>
+
+namespace dq {
+
+namespace {
+
+constexpr int QP_B = 16;         // panel width
+constexpr int QP_SR = 32;        // sketch rows (b + p, p = 16)
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+// Omega[i][r] = +-1: bit i of a 32-bit mix of the ROW index r (oracle/panel_qr.py::omega_sign is the same function)
+__device__ __forceinline__ unsigned qp_row_bits(unsigned r) {
+    unsigned h = r * 0x9E3779B1u + 0x85EBCA77u;
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return h;
+}
+__device__ __forceinline__ double qp_sign(unsigned bits, int i) {
+    return __hiloint2double((int)(0x3FF00000u | (((bits >> i) & 1u) << 31)), 0);
+}
+
+// lane-wise sum over the four 16-lane rows of a wave (gfx950 v_permlane16_swap / v_permlane32_swap), result in every lane
+__device__ __forceinline__ double rows4_sum(double x) {
+    const unsigned lo = (unsigned)__double_as_longlong(x), hi = (unsigned)(__double_as_longlong(x) >> 32);
+    auto l16 = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    auto h16 = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    const double e = __hiloint2double((int)h16[0], (int)l16[0]), o = __hiloint2double((int)h16[1], (int)l16[1]);   // even row | odd row of each pair
+    const double s = e + o;
+    const unsigned slo = (unsigned)__double_as_longlong(s), shi = (unsigned)(__double_as_longlong(s) >> 32);
+    auto l32 = __builtin_amdgcn_permlane32_swap(slo, slo, false, false);
+    auto h32 = __builtin_amdgcn_permlane32_swap(shi, shi, false, false);
+    return __hiloint2double((int)h32[0], (int)l32[0]) + __hiloint2double((int)h32[1], (int)l32[1]);               // lower half | upper half
+}
+
+// d += a[lane J of this 16-lane row] * a  (own value times the broadcast one, one register).  No wait state in front: the callers
+// fence every register these blocks read (dpp_fence) after its last VALU write.
+template <int J>
+__device__ __forceinline__ void dpp_fmac_self(double& d, double a) {
+    asm volatile("v_fmac_f64_dpp %0, %1, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(d) : "v"(a), "n"(J));
+}
+// a += a[lane J] * m
+template <int J>
+__device__ __forceinline__ void dpp_axpy_self(double& a, double m) {
+    asm volatile("v_fmac_f64_dpp %0, %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(a) : "v"(m), "n"(J));
+}
+// every VALU write of a[] issued so far is complete and two wait states old: what a DPP read of these registers needs (the hazard
+// recogniser does not look inside inline asm)
+__device__ __forceinline__ void dpp_fence(double (&a)[16]) {
+    asm volatile("s_nop 1" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]),
+                             "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]));
+}
+
+__device__ __forceinline__ void dpp_fence1(double& z) { asm volatile("s_nop 1" : "+v"(z)); }
+// d += z[lane T of this 16-lane row] * y
+template <int T>
+__device__ __forceinline__ void dpp_fmac(double& d, double z, double y) {
+    asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(d) : "v"(z), "v"(y), "n"(T));
+}
+// tj += sum over t < J of trow[t] * z[lane t of this row]
+template <int... Ts>
+__device__ __forceinline__ void t_row_dot(double& tj, const double (&trow)[16], double z, std::integer_sequence<int, Ts...>) {
+    (dpp_fmac<Ts>(tj, z, trow[Ts]), ...);
+}
+
+template <int NW>
+struct PanelShared {
+    static constexpr int NWP = NW < 2 ? 2 : NW;
+    alignas(16) unsigned long long key[2][NWP];   // selection: every wave's best {norm^2 | column}, double-buffered on the step parity
+    alignas(16) double cand[2][NW][QP_SR + 2];    // ... and that column's residual sketch (rows j..31)
+    alignas(16) double part[2][QP_B][NWP];        // panel: per wave partial x^T a_c, [column][wave]
+    alignas(16) double prow[2][QP_B];             // panel: row k + j of the panel before step j
+    int sel[QP_B];
+};
+
+// dlarfg for (alpha, sum of squares below): H = I - tau v v^T, v = (1, x * scale), H (alpha, x) = (beta, 0).
+// 1 / sqrt and 1 / (alpha - beta) by v_rsq_f64 / v_rcp_f64 + NEWTON Newton steps instead of the IEEE sqrt and two divisions (60
+// dependent instructions on every lane, on the critical path of every step): NEWTON = 2 is good to an ulp or two -- tau, beta and
+// the reflector stay consistent to working precision, which is what the orthogonality of H needs --, NEWTON = 1 (sketch: the
+// selection only ranks columns) to ~1e-8.
+template <int NEWTON>
+__device__ __forceinline__ void householder(double alpha, double tail2, double& beta, double& tau, double& scale) {
+    const double s = fma(alpha, alpha, tail2);
+    double r = __builtin_amdgcn_rsq(s);
+    const double h = 0.5 * s;
+#pragma unroll
+    for (int it = 0; it < NEWTON; ++it) r = r * fma(-h * r, r, 1.5);
+    double sq = s * r;
+    if (NEWTON > 1) sq = fma(0.5 * r, fma(-sq, sq, s), sq);
+    const double b = -copysign(sq, alpha);
+    const double d = alpha - b;                                        // |alpha| + sqrt(s): no cancellation
+    double id = __builtin_amdgcn_rcp(d);
+#pragma unroll
+    for (int it = 0; it < NEWTON; ++it) id = id * fma(-d, id, 2.0);
+    const bool none = tail2 == 0.0;                                    // H = I
+    beta = none ? alpha : b;
+    tau = none ? 0.0 : d * copysign(r, alpha);                         // (beta - alpha) / beta = -d / beta = d * sign(alpha) / sqrt(s)
+    scale = none ? 0.0 : id;
+}
+
+// ---- selection: step J of the column-pivoted QR of the sketch ----
+template <int J, int NW>
+__device__ __forceinline__ void select_step(double (&y)[QP_SR], bool& live, int col, int lane, int wave, PanelShared<NW>& sh) {
+    constexpr int par = J & 1;
+    double tail = 0.0;
+#pragma unroll
+    for (int i = J + 1; i < QP_SR; ++i) tail = fma(y[i], y[i], tail);
+    const double nrm2 = fma(y[J], y[J], tail);
+    // {norm^2 with its low 11 bits dropped | 1024 - column}: one wave maximum decides, the lowest column wins a tie
+    const unsigned long long key = live ? (((unsigned long long)__double_as_longlong(nrm2) & ~0x7FFULL) | (unsigned long long)(1024 - col)) : 0ULL;
+    const unsigned long long wmax = wave_max_u64(key);
+    if (wmax != 0ULL && key == wmax) {          // this wave's candidate publishes BEFORE the winner among the waves is known
+        sh.key[par][wave] = wmax;
+#pragma unroll
+        for (int i = J & ~1; i < QP_SR; i += 2) *reinterpret_cast<double2*>(&sh.cand[par][wave][i]) = double2{y[i], y[i + 1]};
+        sh.cand[par][wave][QP_SR] = tail;
+    }
+    if (wmax == 0ULL && lane == 0) sh.key[par][wave] = 0ULL;
+    __syncthreads();
+    unsigned long long best = sh.key[par][0]; int ww = 0;
+#pragma unroll
+    for (int q = 1; q < NW; ++q) { const unsigned long long o = sh.key[par][q]; if (o > best) { best = o; ww = q; } }
+    const int pcol = 1024 - (int)(best & 0x7FFULL);
+    const double* xs = sh.cand[par][ww];
+    double x[QP_SR];
+#pragma unroll
+    for (int i = J & ~1; i < QP_SR; i += 2) { const double2 v = *reinterpret_cast<const double2*>(&xs[i]); x[i] = v.x; x[i + 1] = v.y; }
+    double beta, tau, scale;
+    householder<1>(x[J], xs[QP_SR], beta, tau, scale);
+    double dot = 0.0;
+#pragma unroll
+    for (int i = J + 1; i < QP_SR; ++i) dot = fma(x[i], y[i], dot);
+    const double cf = -scale * tau * fma(scale, dot, y[J]);          // y_i -= v_i * tau * (v^T y), v_i = x_i * scale
+#pragma unroll
+    for (int i = J + 1; i < QP_SR; ++i) y[i] = fma(x[i], cf, y[i]);
+    if (col == pcol) live = false;
+    if (lane == 0 && wave == 0) sh.sel[J] = pcol;
+}
+
+// ---- panel: Householder step J on the 16 selected columns ----
+// a[16]: rows 64 wave + 16 g + idx of column sel[c]; isdiag: this lane's rows are the panel's own rows k .. k + 15; rows above the
+// panel (r < k) hold zeros.  x = column J below row k + J: all sources are the registers a[] themselves (row_newbcast:J picks lane J of
+// the 16-lane row); the rows <= k + J of the diagonal block are kept out by summing them separately (dots) / by a zero factor (update).
+// The reflector tails stay UNSCALED in the registers (v_c = x_c * myscale below the diagonal, myscale kept by the lanes of column c,
+// applied at the write-out): no per-step scaling pass, and v_c^T v_J = myscale_c (x_c[k+J] + scale_J x_c^T x_J) comes out of the same dots.
+template <int J, int NW>
+__device__ __forceinline__ void panel_step(double (&a)[16], double (&trow)[QP_B], double& myscale, bool isdiag, bool wave_live, int c, int g, int wave,
+                                           PanelShared<NW>& sh, double* tau_out) {
+    constexpr int par = J & 1;
+    if (wave_live) {
+        double dlo0 = 0.0, dlo1 = 0.0, dhi0 = 0.0, dhi1 = 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            if (i <= J) { if (i & 1) dpp_fmac_self<J>(dlo1, a[i]); else dpp_fmac_self<J>(dlo0, a[i]); }
+            else { if (i & 1) dpp_fmac_self<J>(dhi1, a[i]); else dpp_fmac_self<J>(dhi0, a[i]); }
+        }
+        const double part = rows4_sum((dhi0 + dhi1) + (isdiag ? 0.0 : dlo0 + dlo1));
+        if (g == 0) sh.part[par][c][wave] = part;
+        if (isdiag) sh.prow[par][c] = a[J];
+    } else if (g == 0) sh.part[par][c][wave] = 0.0;
+    __syncthreads();
+    double s_c = sh.part[par][c][0], s_j = sh.part[par][J][0];
+#pragma unroll
+    for (int q = 1; q < NW; ++q) { s_c += sh.part[par][c][q]; s_j += sh.part[par][J][q]; }
+    const double alpha = sh.prow[par][J], apc = sh.prow[par][c];
+    double beta, tau, scale;
+    householder<2>(alpha, s_j, beta, tau, scale);
+    const double zc = fma(scale, s_c, apc);                           // c > J: v_J^T a_c; c < J: v_J^T x_c (x_c = the unscaled tail of v_c)
+    if (c == J) myscale = scale;
+    if (wave_live) {
+        const double mcf = c > J ? -scale * tau * zc : 0.0;
+        const double mlo = isdiag ? 0.0 : mcf;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            if (i <= J) dpp_axpy_self<J>(a[i], mlo);
+            else dpp_axpy_self<J>(a[i], mcf);
+        }
+        const double newd = c > J ? fma(-tau, zc, a[J]) : beta;       // row k + J: v = 1
+        a[J] = (isdiag && c >= J) ? newd : a[J];
+        dpp_fence(a);
+    }
+    // compact WY: T[0:J, J] = -tau T[0:J, 0:J] (V^T v_J), T[J][J] = tau; lane c keeps row c of T
+    if (wave == 0) {
+        double zt = myscale * zc;                                     // (V^T v_J)_c for c < J
+        double tj = 0.0;
+        dpp_fence1(zt);
+        t_row_dot(tj, trow, zt, std::make_integer_sequence<int, J>{});
+        trow[J] = c < J ? -tau * tj : (c == J ? tau : 0.0);
+        if (g == 0 && c == J) tau_out[J] = tau;
+    }
+}
+
+}  // namespace
+
+// One workgroup of NW waves per chain (NW >= n / 64: lane <-> column in the selection, 64 rows per wave in the panel): selects the
+// 16 columns of the panel that starts at step k and factors them.
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void qp_panel_kernel(Mat Am, QrWork w, int n, int k) {
+    __shared__ PanelShared<NW> sh;
+    const int chain = blockIdx.y;
+    double* __restrict__ A = Am.at(chain);
+    double* __restrict__ pw = w.pw + (long)chain * w.pw_stride;
+    const double* __restrict__ Y = pw;                         // [QP_SR][n]
+    double* __restrict__ Vp = pw + (long)QP_SR * n;           // [n][QP_B] column-major clean copy of the panel's reflectors
+    double* __restrict__ Tm = Vp + (long)QP_B * n;            // [QP_B][QP_B] column-major
+    int* __restrict__ pivpos = w.pivpos + (long)chain * w.pivpos_stride;
+    double* tau = w.tau + (long)chain * w.tau_stride;
+    int* jpvt = w.jpvt + (long)chain * w.jpvt_stride;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+
+    // ---- selection ----
+    {
+        const int col = t;
+        bool live = col < n && pivpos[col] < 0;
+        double y[QP_SR];
+#pragma unroll
+        for (int i = 0; i < QP_SR; ++i) y[i] = col < n ? Y[(long)i * n + col] : 0.0;
+#define QP_SEL(J) select_step<J, NW>(y, live, col, lane, wave, sh);
+        QP_SEL(0) QP_SEL(1) QP_SEL(2) QP_SEL(3) QP_SEL(4) QP_SEL(5) QP_SEL(6) QP_SEL(7)
+        QP_SEL(8) QP_SEL(9) QP_SEL(10) QP_SEL(11) QP_SEL(12) QP_SEL(13) QP_SEL(14) QP_SEL(15)
+#undef QP_SEL
+    }
+    __syncthreads();
+    // ---- panel ----
+    const int c = lane & 15, g = lane >> 4;
+    const int mycol = sh.sel[c];
+    const int r0 = 64 * wave + 16 * g;
+    const bool isdiag = r0 == k;
+    const bool wave_live = 64 * wave + 64 > k && 64 * wave < n;         // a wave whose rows all lie above the panel only keeps the barriers (and T: wave 0)
+    double a[16], trow[QP_B], myscale = 0.0;
+    {
+        const double* src = A + (long)n * mycol + r0;
+        const bool rows_live = r0 >= k && r0 < n;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) a[i] = rows_live ? src[i] : 0.0;
+#pragma unroll
+        for (int i = 0; i < QP_B; ++i) trow[i] = 0.0;
+        dpp_fence(a);
+    }
+    double* tau_out = tau + k;
+#define QP_PAN(J) panel_step<J, NW>(a, trow, myscale, isdiag, wave_live, c, g, wave, sh, tau_out);
+    QP_PAN(0) QP_PAN(1) QP_PAN(2) QP_PAN(3) QP_PAN(4) QP_PAN(5) QP_PAN(6) QP_PAN(7)
+    QP_PAN(8) QP_PAN(9) QP_PAN(10) QP_PAN(11) QP_PAN(12) QP_PAN(13) QP_PAN(14) QP_PAN(15)
+#undef QP_PAN
+    // ---- write-out: R0 / beta / reflectors in place, the clean reflector panel (unit diagonal, zeros above), T, jpvt, pivpos ----
+    if (r0 >= k && r0 < n) {
+        double* dst = A + (long)n * mycol + r0;
+        double* vdst = Vp + (long)n * c + r0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const bool below = !isdiag || i > c;                          // strictly below the column's diagonal: the reflector tail
+            const double v = below ? a[i] * myscale : a[i];
+            dst[i] = v;
+            vdst[i] = below ? v : (i == c ? 1.0 : 0.0);
+        }
+    }
+    if (wave == 0 && g == 0) {
+#pragma unroll
+        for (int i = 0; i < QP_B; ++i) Tm[c + QP_B * i] = trow[i];
+        jpvt[k + c] = mycol;
+        pivpos[mycol] = k + c;
+    }
+}
+
+// grid.x = n / 16 column blocks.  UPDATE: A[k:, cols] <- (I - V T V^T)^T A[k:, cols] for the live columns of the block, then the
+// sketch of rows >= k + 16 of the result; !UPDATE (before the first panel): pivpos = -1 and the sketch of A itself.
+template <bool UPDATE>
+__global__ __launch_bounds__(256) void qp_update_kernel(Mat Am, QrWork w, int n, int k) {
+    __shared__ double red[4][QP_SR / 16 * 4][64];                // per wave partial tiles (W: 4 registers, Y: 8 registers)
+    const int chain = blockIdx.y;
+    double* __restrict__ A = Am.at(chain);
+    double* __restrict__ pw = w.pw + (long)chain * w.pw_stride;
+    double* __restrict__ Y = pw;
+    const double* __restrict__ Vp = pw + (long)QP_SR * n;
+    const double* __restrict__ Tm = Vp + (long)QP_B * n;
+    int* __restrict__ pivpos = w.pivpos + (long)chain * w.pivpos_stride;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int r16 = lane & 15, kk = lane >> 4;
+    const int col = 16 * blockIdx.x + r16;
+    bool live_col = true;
+    if (UPDATE) {
+        live_col = pivpos[col] < 0;
+        if (__ballot(live_col) == 0ULL) return;                  // every wave sees the same 16 columns: a uniform exit
+    } else if (t < 16) pivpos[col] = -1;
+    double* __restrict__ Ac = A + (long)n * col;
+    const int m_tiles = (n - k) / 16;
+    d4 wp = {0.0, 0.0, 0.0, 0.0};
+    if (UPDATE) {
+        // W = V^T A_blk: K = rows k .. n-1, split over the four waves; lane (x, kk) feeds rows base + 4 kk + s to k-step s
+        d4 acc = {0.0, 0.0, 0.0, 0.0};
+        for (int rt = wave; rt < m_tiles; rt += 4) {
+            const int rb = k + 16 * rt + 4 * kk;
+            const double* vsrc = Vp + (long)n * r16 + rb;
+            const double* asrc = Ac + rb;
+            double av[4], bv[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) { av[s] = vsrc[s]; bv[s] = asrc[s]; }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s], bv[s], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave][r][lane] = acc[r];
+        __syncthreads();
+        d4 W;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) W[r] = live_col ? (red[0][r][lane] + red[1][r][lane]) + (red[2][r][lane] + red[3][r][lane]) : 0.0;
+        // W' = T^T W: a = T[i = kk + 4 s][i' = r16], b = W[kk + 4 s][c] (the accumulator registers as they are)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) wp = __builtin_amdgcn_mfma_f64_16x16x4f64(Tm[(kk + 4 * s) + QP_B * r16], W[s], wp, 0, 0, 0);
+        __syncthreads();
+    }
+    d4 ya[QP_SR / 16];
+#pragma unroll
+    for (int yt = 0; yt < QP_SR / 16; ++yt) ya[yt] = d4{0.0, 0.0, 0.0, 0.0};
+    for (int rt = wave; rt < m_tiles; rt += 4) {
+        const int r0 = k + 16 * rt;
+        d4 acc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = Ac[r0 + kk + 4 * r];
+        if (UPDATE) {
+            const double* vsrc = Vp + r0 + r16;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-vsrc[(long)n * (kk + 4 * s)], wp[s], acc, 0, 0, 0);
+            if (live_col) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Ac[r0 + kk + 4 * r] = acc[r];
+            }
+        }
+        if (!UPDATE || rt >= 1) {                                  // rows of the NEXT trailing matrix: sketch them while they are in registers
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const unsigned bits = qp_row_bits((unsigned)(r0 + kk + 4 * s));
+#pragma unroll
+                for (int yt = 0; yt < QP_SR / 16; ++yt) ya[yt] = __builtin_amdgcn_mfma_f64_16x16x4f64(qp_sign(bits, 16 * yt + r16), acc[s], ya[yt], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int yt = 0; yt < QP_SR / 16; ++yt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave][4 * yt + r][lane] = ya[yt][r];
+    __syncthreads();
+    for (int idx = t; idx < QP_SR / 16 * 4 * 64; idx += 256) {
+        const int l = idx & 63, q = idx >> 6, yt = q >> 2, r = q & 3;
+        const double v = (red[0][q][l] + red[1][q][l]) + (red[2][q][l] + red[3][q][l]);
+        Y[(long)(16 * yt + (l >> 4) + 4 * r) * n + 16 * blockIdx.x + (l & 15)] = v;
+    }
+}
+
+bool qr_panel_ok(int n, const QrWork& w) { return n >= 16 && n <= 1024 && n % 16 == 0 && w.pw != nullptr && w.pivpos != nullptr && w.pw_stride >= qr_panel_work_doubles(n); }
+long qr_panel_work_doubles(int n) { return (long)(QP_SR + QP_B) * n + QP_B * QP_B; }
+
+int launch_qr_panel(Mat A, QrWork w, int n, int n_chains, hipStream_t s) {
+    if (!qr_panel_ok(n, w)) { set_error("panel QR: n must be a multiple of 16 in [16, 1024] and the workspace present"); return -1; }
+    const dim3 ugrid(n / 16, n_chains);
+    const int nw = (n + 63) / 64;
+    hipLaunchKernelGGL((qp_update_kernel<false>), ugrid, dim3(256), 0, s, A, w, n, 0);
+    for (int k = 0; k < n; k += QP_B) {
+#define QP_LAUNCH(NW) hipLaunchKernelGGL((qp_panel_kernel<NW>), dim3(1, n_chains), dim3(64 * NW), 0, s, A, w, n, k)
+        if (nw <= 1) QP_LAUNCH(1); else if (nw <= 2) QP_LAUNCH(2); else if (nw <= 4) QP_LAUNCH(4); else if (nw <= 8) QP_LAUNCH(8);
+        else if (nw <= 10) QP_LAUNCH(10); else QP_LAUNCH(16);
+#undef QP_LAUNCH
+        if (k + QP_B < n) hipLaunchKernelGGL((qp_update_kernel<true>), ugrid, dim3(256), 0, s, A, w, n, k);
+    }
+    DQ_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace dq

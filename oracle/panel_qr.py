@@ -98,16 +98,19 @@ def omega(rows, n, seed=20240229):
 
 
 def omega_sign(rows, n):
-    """Rademacher sketching matrix from an integer hash of (row, column): Omega[i, r] = +-1.  This is the matrix the HIP
-    kernels generate in registers (dqmc_amd/csrc/qr_panel.hip: `sketch_sign`), so the products Omega . A are sums of +-a_rc."""
+    """Rademacher sketching matrix from an integer hash of the ROW index r of the matrix: Omega[i, r] = -1 when bit i of
+    fmix32(r * 0x9E3779B1 + 0x85EBCA77) is set, +1 otherwise (rows <= 32).  The same function as `qp_row_bits` / `qp_sign`
+    of dqmc_amd/csrc/qr_panel.hip, which generate the matrix in registers: the products Omega . A are sums of +-a_rc."""
+    assert rows <= 32
     key = (rows, n, "sign")
     if key not in _OMEGA:
-        i = np.arange(rows, dtype=np.uint64)[:, None]; r = np.arange(n, dtype=np.uint64)[None, :]
-        h = (i * np.uint64(0x9E3779B1) + r * np.uint64(0x85EBCA77) + np.uint64(0xC2B2AE3D)) & np.uint64(0xFFFFFFFF)
-        h ^= h >> np.uint64(15); h = (h * np.uint64(0x2C1B3C6D)) & np.uint64(0xFFFFFFFF)
-        h ^= h >> np.uint64(12); h = (h * np.uint64(0x297A2D39)) & np.uint64(0xFFFFFFFF)
-        h ^= h >> np.uint64(15)
-        _OMEGA[key] = np.where((h & np.uint64(1)) == 1, -1.0, 1.0)
+        M32 = np.uint64(0xFFFFFFFF)
+        h = (np.arange(n, dtype=np.uint64) * np.uint64(0x9E3779B1) + np.uint64(0x85EBCA77)) & M32
+        h ^= h >> np.uint64(16); h = (h * np.uint64(0x85EBCA6B)) & M32
+        h ^= h >> np.uint64(13); h = (h * np.uint64(0xC2B2AE35)) & M32
+        h ^= h >> np.uint64(16)
+        bits = (h[None, :] >> np.arange(rows, dtype=np.uint64)[:, None]) & np.uint64(1)
+        _OMEGA[key] = np.where(bits == 1, -1.0, 1.0)
     return _OMEGA[key]
 
 

@@ -53,7 +53,24 @@ def test_gemm(hip, n):
     assert close(hip.gemm(np.eye(n), B), B, 1e-15)
 
 
-@pytest.mark.parametrize("n", [4, 16, 36, 64, 100, 256, 272, 300, 576, 640])       # n > 256: the cooperative multi-workgroup QRCP (qr_coop.hip)
+def panel_path(n):
+    """to_LDR takes the panel-pivoted blocked QR (qr_panel.hip) at these sizes: one pivot decision per 16 columns, so L, d, R are
+    a DIFFERENT rank-revealing factorisation of the same matrix than dgeqp3's (triples are compared as products)."""
+    return n % 16 == 0 and 64 <= n <= 1024 and os.environ.get("DQMC_QR_PANEL") != "0"
+
+
+def ldr_quality(F):
+    """(max |R_ij|, worst grading violation max_{j > i} d_j / d_i): both are <= 1 for dgeqp3; a factorisation is rank-revealing enough
+    for the stabilised products as long as both stay O(1) (the numpy evaluation of the panel scheme: <= 2.2 on the DQMC matrices)."""
+    L, d, R = F
+    suf = np.maximum.accumulate(d[::-1])[::-1]
+    return float(np.abs(R).max()), float((suf[1:] / d[:-1]).max()) if len(d) > 1 else 0.0
+
+
+PANEL_QUALITY = 8.0
+
+
+@pytest.mark.parametrize("n", [4, 16, 36, 64, 100, 128, 256, 272, 300, 512, 576, 640, 1024])   # 64 <= n, n % 16 == 0: qr_panel.hip; else qr_colown / qr_coop
 def test_to_ldr(hip, orc, n):
     rng = np.random.default_rng(100 + n)
     M = graded(rng, n)
@@ -61,9 +78,52 @@ def test_to_ldr(hip, orc, n):
     Lo, do, Ro = orc.to_ldr(M)
     assert np.abs(L.T @ L - np.eye(n)).max() < 1e-13 * n
     assert np.abs(ldr_mat((L, d, R)) - M).max() < 1e-13 * n * np.abs(M).max()
-    assert np.allclose(d, do, rtol=1e-10)                  # same pivot order, same |diag R0|
-    assert np.all(np.diff(d) <= 1e-12 * d[:-1])            # non-increasing (true column pivoting)
-    assert close(R, Ro, 1e-9) and close(np.abs(L), np.abs(Lo), 1e-9)
+    assert (np.abs(ldr_mat((L, d, R)) - M).max(axis=0) / np.abs(M).max(axis=0)).max() < 1e-12 * n     # column by column: small columns are not hidden behind max|M|
+    if panel_path(n):
+        rmax, grade = ldr_quality((L, d, R))
+        print(f"n = {n}: panel-pivoted to_LDR max|R| = {rmax:.2f}, grading {grade:.2f}")
+        assert rmax <= PANEL_QUALITY and grade <= PANEL_QUALITY
+        # the same singular-value profile as the column-pivoted factorisation: both bracket sigma_i within small factors
+        assert np.abs(np.log(np.sort(d)[::-1] / do)).max() < np.log(PANEL_QUALITY)
+        # each row of R is the unit-pivot row of R0 / |r_ii|: exactly one entry of modulus 1 per row in the pivot's column
+        assert np.allclose(np.sort(np.abs(R), axis=1)[:, -1] >= 1.0 - 1e-14, True)
+    else:
+        assert np.allclose(d, do, rtol=1e-10)                  # same pivot order, same |diag R0|
+        assert np.all(np.diff(d) <= 1e-12 * d[:-1])            # non-increasing (true column pivoting)
+        assert close(R, Ro, 1e-9) and close(np.abs(L), np.abs(Lo), 1e-9)
+
+
+@pytest.mark.parametrize("kind", ["columns", "rows", "both"])
+@pytest.mark.parametrize("n", [64, 256, 576])
+def test_to_ldr_panel_on_strongly_graded_matrices(hip, n, kind):
+    """The three shapes to_LDR sees in a sweep -- (M L) diag(d) (columns graded: mat_mul_ldr), diag(d) (R M) (rows graded:
+    ldr_mul_mat), both (ldr_mul_ldr) -- over 24 orders of magnitude: orthogonality, column-wise reconstruction and the grading of d."""
+    rng = np.random.default_rng(900 + n)
+    X = rng.standard_normal((n, n)); s1 = np.exp(rng.uniform(-28, 28, n)); s2 = np.exp(rng.uniform(-28, 28, n))
+    M = X * s1[None, :] if kind == "columns" else (s1[:, None] * X if kind == "rows" else s1[:, None] * X * s2[None, :])
+    L, d, R = hip.to_ldr(M)
+    assert np.abs(L.T @ L - np.eye(n)).max() < 1e-13 * n
+    assert (np.abs(ldr_mat((L, d, R)) - M).max(axis=0) / np.abs(M).max(axis=0)).max() < 1e-12 * n
+    rmax, grade = ldr_quality((L, d, R))
+    print(f"n = {n} {kind}: max|R| = {rmax:.2f}, grading {grade:.2f}")
+    assert rmax <= PANEL_QUALITY and grade <= PANEL_QUALITY
+
+
+def test_to_ldr_column_pivoted_kernels_in_subprocess(hip):
+    """DQMC_QR_PANEL=0 keeps dgeqp3's own pivot order at every size (qr_colown.hip, qr_coop.hip): the oracle's d, R and |L| element-wise."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); import dqmc_amd, oracle\n"
+            "hip = dqmc_amd.lib(); orc = oracle.oracle(); orc.set_backend('builtin')\n"
+            "for n in (64, 256, 576):\n"
+            "    M = np.random.default_rng(100 + n).standard_normal((n, n)) * np.exp(np.random.default_rng(7 + n).uniform(-6, 6, n))[None, :]\n"
+            "    L, d, R = hip.to_ldr(M); Lo, do, Ro = orc.to_ldr(M)\n"
+            "    assert np.allclose(d, do, rtol=1e-10) and np.all(np.diff(d) <= 1e-12 * d[:-1]), n\n"
+            "    assert np.abs(R - Ro).max() <= 1e-9 * np.abs(Ro).max() and np.abs(np.abs(L) - np.abs(Lo)).max() <= 1e-9, n\n"
+            "print('ok')") % root
+    env = dict(os.environ); env["DQMC_QR_PANEL"] = "0"
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
 
 
 @pytest.mark.parametrize("n", [16, 36, 64, 100, 128, 144, 256])
@@ -76,7 +136,8 @@ def test_ldr_products_and_inverses(hip, orc, n):
                      (hip.ldr_mul_ldr(F1, F2), orc.ldr_mul_ldr(F1, F2))]:
         ref_m = ldr_mat(ref)
         assert np.abs(ldr_mat(got) - ref_m).max() < 1e-11 * np.abs(ref_m).max()
-        assert np.allclose(got[1], ref[1], rtol=1e-9)
+        if panel_path(n): assert max(ldr_quality(got)) <= PANEL_QUALITY
+        else: assert np.allclose(got[1], ref[1], rtol=1e-9)
     G, ld = hip.inv_I_plus_ldr(F1); Go, ldo = orc.inv_I_plus_ldr(F1)
     assert close(G, Go) and abs(ld - ldo) < 1e-9 * max(1.0, abs(ldo))
     G2 = hip.inv_I_plus_ldr_mul_ldr(F1, F2); G2o = orc.inv_I_plus_ldr_mul_ldr(F1, F2)
@@ -453,7 +514,7 @@ def test_alternative_kernel_paths_in_subprocess(hip):
         assert out.returncode == 0, (env_extra, out.stderr[-2000:])
         return json.loads(out.stdout.strip().splitlines()[-1])
     for env in ({}, {"DQMC_WALK_SUBMATRIX": "1"}, {"DQMC_SLICE_MULTIKERNEL": "1"}, {"DQMC_SLICE_PAIRS": "1"}, {"DQMC_SLICE_SOLO": "1"}, {"DQMC_LU_CLASSIC": "1"},
-                {"DQMC_QR_STREAMING": "1"}, {"DQMC_INIT_SEQUENTIAL": "1"}):
+                {"DQMC_QR_STREAMING": "1"}, {"DQMC_QR_PANEL": "0"}, {"DQMC_INIT_SEQUENTIAL": "1"}):
         got = run(env)
         print(env, {k: (v["d0"], v["dA"]) if "d0" in v else v["dA"] for k, v in got.items()})
         for name in ("cfg2_therm", "cfg3_therm"):
@@ -480,7 +541,7 @@ def test_alternative_kernel_paths_above_256_in_subprocess(hip):
             "    e = m.engine(dqmc_amd.lib()); e.set_fields(f); e.init(); G0 = e.get_G(); e.sweep_0_to_beta(*st)\n"
             "    np.savez(sys.argv[1] + str(L) + '.npz', G0=G0, G1=e.get_G(), f=e.get_fields(), acc=e.stats().n_accepted)\n") % root
     ref = {L: body(L) for L in (24, 20)}
-    for env in ({"DQMC_GEMM_NO_STAGE32": "1"}, {"DQMC_GJ_MAX_N": "256"}, {"DQMC_QR_STREAMING": "1"}, {"DQMC_SLICE_MULTIKERNEL": "1"}):
+    for env in ({"DQMC_GEMM_NO_STAGE32": "1"}, {"DQMC_GJ_MAX_N": "256"}, {"DQMC_QR_STREAMING": "1"}, {"DQMC_QR_PANEL": "0"}, {"DQMC_SLICE_MULTIKERNEL": "1"}):
         with tempfile.TemporaryDirectory() as td:
             e2 = dict(os.environ); e2.update(env)
             out = subprocess.run([sys.executable, "-c", code, os.path.join(td, "r")], env=e2, capture_output=True, text=True, timeout=600)
@@ -791,7 +852,7 @@ def test_persistent_submatrix_kernel_abandons_the_rest_of_a_sweep_when_the_grid_
         pytest.skip("no CU reservation left for a persistent slice kernel")
     e.set_fields(f0); e.init()
     with pytest.raises(DqmcError) as ei:
-        e.sweep_0_to_beta(*sf)
+        e.sweep_0_to_beta(*sf); e.sync()                           # the sweep is enqueued asynchronously: the error surfaces at the next synchronising call
     assert ei.value.code == -3 and "time slice 4" in str(ei.value), str(ei.value)
     assert e.slice_path() == 0                                     # kernel pairs from now on
     # the oracle walks slices 0..3 of the same stream and only wraps through the rest
