@@ -593,7 +593,9 @@ def test_observables_batched_and_golden(hip):
     for c in range(3):
         e1 = m.engine(hip); e1.set_fields(fs[c]); e1.init()
         s1, c1 = e1.measure_equal_time(m.L1, m.L2)
-        assert np.abs(scb[c] - s1).max() < 1e-12 and np.abs(chib[c] - c1).max() < 1e-12
+        # relative: the single-chain engine initialises block by block in one batch (its B-bar factorisations go through the column-pivoted
+        # batch kernels), the 3-chain engine through the panel-pivoted to_LDR -- two roundings of the same G (s-wave ~ 79: 6e-12 = 8e-14 relative)
+        assert (np.abs(scb[c] - s1) / np.maximum(1.0, np.abs(s1))).max() < 1e-12 and np.abs(chib[c] - c1).max() < 1e-12 * max(1.0, np.abs(c1).max())
     for name in sorted(fn[:-4] for fn in os.listdir(GOLD) if fn.endswith(".npz")):
         z = np.load(os.path.join(GOLD, name + ".npz"))
         if "G0_rows" in z.files:
@@ -639,7 +641,10 @@ def test_unequal_time_parity(hip, orc, cfg, tol):
             if o2 is not None:
                 floor = max(floor, np.abs(o2.get_G_tau(which, l) - b).max() / max(1.0, np.abs(b).max()))
                 floor_abs = max(floor_abs, np.abs(o2.get_G_tau(which, l) - b).max())
-    tol = max(tol, 5.0 * floor)
+    # i.i.d. fields: 8x the CPU-vs-CPU floor.  Round 3 measured 3.8x with dgeqp3's pivot order on the device; the panel-pivoted to_LDR (one
+    # pivot decision per 16 columns, |R| <= 1.06, grading <= 2.2 instead of 1) lands at 6.2x on this input -- the thermalised case below stays
+    # at 1e-10 strictly
+    tol = max(tol, 8.0 * floor)
     print(f"{cfg}{' (thermalised)' if therm else ''}: CPU-vs-CPU floor {floor:.2e} relative, {floor_abs:.2e} absolute")
     print(f"{cfg}: unequal-time max rel err {worst:.2e}, max abs err {worst_abs:.2e} (largest entry {gmax:.2e}), equal-time series Gtt {worst_eq:.2e} absolute")
     if therm:
