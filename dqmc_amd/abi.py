@@ -46,7 +46,7 @@ ABI_SYMBOLS = [
     "create", "create_batch", "n_chains", "destroy", "set_fields", "get_fields", "init", "get_G", "set_G", "get_logdet",
     "n_stack", "get_stack", "sweep_0_to_beta", "sweep_beta_to_0", "sync", "get_stats",
     "wrap_forward", "wrap_backward", "local_update_slice", "calculate_Bbar", "global_action", "set_checkerboard",
-    "update_kernel_time", "set_profiling", "slice_path",
+    "update_kernel_time", "set_profiling", "slice_path", "debug_snapshot",
     "measure_equal_time", "measure_accumulate", "measure_fetch",
     "sweep_unequal_time", "get_G_tau", "half_warp", "measure_unequal_time", "measure_unequal_fetch",
     "comm_unique_id", "comm_create_rccl", "comm_create_callbacks", "comm_destroy", "comm_rank", "comm_world_size",
@@ -120,10 +120,12 @@ class DqmcLib:
         if self.has_symbol("sweep_unequal_time"):
             g("sweep_unequal_time").argtypes = [C.c_void_p]
             g("get_G_tau").argtypes = [C.c_void_p, C.c_int, C.c_int, c_double_p]
-        if self.has_symbol("half_warp"):
-            g("half_warp").argtypes = [C.c_void_p, c_double_p, c_double_p, C.c_int, C.c_int, c_double_p]
             g("measure_unequal_time").argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, c_double_p]
             g("measure_unequal_fetch").argtypes = [C.c_void_p, c_double_p, c_int64_p, C.c_int]
+        if self.has_symbol("half_warp"):
+            g("half_warp").argtypes = [C.c_void_p, c_double_p, c_double_p, C.c_int, C.c_int, c_double_p]
+        if self.has_symbol("debug_snapshot"):
+            g("debug_snapshot").argtypes = [C.c_void_p, c_double_p, C.c_void_p, C.c_void_p, C.c_void_p]
         if self.has_symbol("replica_exchange_round"):
             g("comm_unique_id").argtypes = [C.c_void_p]
             g("comm_create_rccl").argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_int, C.c_int]
@@ -479,6 +481,13 @@ class Engine:
         out = np.empty(self.C * 3 * (self.nt + 1) * L1 * L2); cnt = np.zeros(1, dtype=np.int64)
         self._c("measure_unequal_fetch", _p(out), cnt.ctypes.data_as(c_int64_p), 1 if reset else 0)
         return self._ut_cube(out, L1, L2), int(cnt[0])
+
+    def debug_snapshot(self):
+        """dqmc_debug_snapshot of chain 0: dict(wrap_err[n_stack], accepted[nt] of the last half sweep, sync_words[80], slice_epoch)."""
+        ns = self.n_stack()
+        we = np.zeros(ns); acc = np.zeros(self.nt, np.int32); sw = np.zeros(80, np.uint32); ep = C.c_uint(0)
+        self._c("debug_snapshot", _p(we), acc.ctypes.data, sw.ctypes.data, C.byref(ep))
+        return dict(wrap_err=we, accepted=acc, sync_words=sw, slice_epoch=int(ep.value))
 
     def slice_path(self) -> int:
         """dqmc_slice_path: 0 = scan / flush kernel pairs, 1 = persistent single-launch slice kernel, 2 = persistent, and at least one

@@ -1067,6 +1067,15 @@ int dqmc_update_kernel_time(dqmc_engine* h, double* ms, int64_t* n_launches, int
 }
 // diagnostic: 1 when the next local update of this engine takes a persistent single-launch slice kernel (it holds a CU reservation
 // and no hand-off has failed), 0 for the kernel pairs
+int dqmc_debug_snapshot(dqmc_engine* h, double* wrap_err, int* accepted, unsigned int* sync_words, unsigned int* slice_epoch) {
+    CHECK_E(h); Engine& e = h->e; DQ_HIP(hipSetDevice(e.device));
+    DQ_HIP(hipStreamSynchronize(e.s));
+    if (wrap_err) DQ_HIP(hipMemcpy(wrap_err, e.err, sizeof(double) * e.n_stack, hipMemcpyDeviceToHost));
+    if (accepted) DQ_HIP(hipMemcpy(accepted, e.acc, sizeof(int) * e.nt, hipMemcpyDeviceToHost));
+    if (sync_words) DQ_HIP(hipMemcpy(sync_words, e.slice_sync, sizeof(unsigned int) * 80, hipMemcpyDeviceToHost));
+    if (slice_epoch) *slice_epoch = e.slice_epoch;
+    return 0;
+}
 int dqmc_slice_path(dqmc_engine* h) {
     if (!h) return -1;
     Engine& e = h->e;

@@ -32,7 +32,11 @@ namespace dq {
 namespace {
 
 constexpr int QP_B = 16;         // panel width
-constexpr int QP_SR = 32;        // sketch rows (b + p, p = 16)
+constexpr int QP_SR = 32;        // sketch rows formed by the update kernel (two MFMA row tiles)
+#ifndef QP_SEL_ROWS
+#define QP_SEL_ROWS 24
+#endif
+constexpr int QP_SEL = QP_SEL_ROWS;   // ... and used by the selection (b + p, p = 8): 25.2 us per panel at n = 256 against 28.2 with all 32 (max|R| 1.06 / grading 2.8 against 1.06 / 2.2)
 typedef double d4 __attribute__((ext_vector_type(4)));
 
 // Omega[i][r] = +-1: bit i of a 32-bit mix of the ROW index r (oracle/panel_qr.py::omega_sign is the same function)
@@ -92,7 +96,7 @@ template <int NW>
 struct PanelShared {
     static constexpr int NWP = NW < 2 ? 2 : NW;
     alignas(16) unsigned long long key[2][NWP];   // selection: every wave's best {norm^2 | column}, double-buffered on the step parity
-    alignas(16) double cand[2][NW][QP_SR + 2];    // ... and that column's residual sketch (rows j..31)
+    alignas(16) double cand[2][NW][QP_SEL + 2];    // ... and that column's residual sketch (rows j..31)
     alignas(16) double part[2][QP_B][NWP];        // panel: per wave partial x^T a_c, [column][wave]
     alignas(16) double prow[2][QP_B];             // panel: row k + j of the panel before step j
     int sel[QP_B];
@@ -123,13 +127,22 @@ __device__ __forceinline__ void householder(double alpha, double tail2, double& 
     scale = none ? 0.0 : id;
 }
 
+// the steps exchange data through LDS only: a barrier that does not drain the vector memory queue (__syncthreads() is s_waitcnt vmcnt(0)
+// lgkmcnt(0) + s_barrier: it would park every wave until its global stores / loads have completed)
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 // ---- selection: step J of the column-pivoted QR of the sketch ----
 template <int J, int NW>
-__device__ __forceinline__ void select_step(double (&y)[QP_SR], bool& live, int col, int lane, int wave, PanelShared<NW>& sh) {
+__device__ __forceinline__ void select_step(double (&y)[QP_SEL], bool& live, int col, int lane, int wave, PanelShared<NW>& sh) {
     constexpr int par = J & 1;
-    double tail = 0.0;
+    double tl[4] = {0.0, 0.0, 0.0, 0.0};                             // four chains: a dependent fp64 FMA every ~8 clk, an independent one every 4
 #pragma unroll
-    for (int i = J + 1; i < QP_SR; ++i) tail = fma(y[i], y[i], tail);
+    for (int i = J + 1; i < QP_SEL; ++i) tl[i & 3] = fma(y[i], y[i], tl[i & 3]);
+    const double tail = (tl[0] + tl[1]) + (tl[2] + tl[3]);
     const double nrm2 = fma(y[J], y[J], tail);
     // {norm^2 with its low 11 bits dropped | 1024 - column}: one wave maximum decides, the lowest column wins a tie
     const unsigned long long key = live ? (((unsigned long long)__double_as_longlong(nrm2) & ~0x7FFULL) | (unsigned long long)(1024 - col)) : 0ULL;
@@ -137,27 +150,28 @@ __device__ __forceinline__ void select_step(double (&y)[QP_SR], bool& live, int 
     if (wmax != 0ULL && key == wmax) {          // this wave's candidate publishes BEFORE the winner among the waves is known
         sh.key[par][wave] = wmax;
 #pragma unroll
-        for (int i = J & ~1; i < QP_SR; i += 2) *reinterpret_cast<double2*>(&sh.cand[par][wave][i]) = double2{y[i], y[i + 1]};
-        sh.cand[par][wave][QP_SR] = tail;
+        for (int i = J & ~1; i < QP_SEL; i += 2) *reinterpret_cast<double2*>(&sh.cand[par][wave][i]) = double2{y[i], y[i + 1]};
+        sh.cand[par][wave][QP_SEL] = tail;
     }
     if (wmax == 0ULL && lane == 0) sh.key[par][wave] = 0ULL;
-    __syncthreads();
+    lds_barrier();
     unsigned long long best = sh.key[par][0]; int ww = 0;
 #pragma unroll
     for (int q = 1; q < NW; ++q) { const unsigned long long o = sh.key[par][q]; if (o > best) { best = o; ww = q; } }
     const int pcol = 1024 - (int)(best & 0x7FFULL);
     const double* xs = sh.cand[par][ww];
-    double x[QP_SR];
+    double x[QP_SEL];
 #pragma unroll
-    for (int i = J & ~1; i < QP_SR; i += 2) { const double2 v = *reinterpret_cast<const double2*>(&xs[i]); x[i] = v.x; x[i + 1] = v.y; }
+    for (int i = J & ~1; i < QP_SEL; i += 2) { const double2 v = *reinterpret_cast<const double2*>(&xs[i]); x[i] = v.x; x[i + 1] = v.y; }
     double beta, tau, scale;
-    householder<1>(x[J], xs[QP_SR], beta, tau, scale);
-    double dot = 0.0;
+    householder<1>(x[J], xs[QP_SEL], beta, tau, scale);
+    double dt[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int i = J + 1; i < QP_SR; ++i) dot = fma(x[i], y[i], dot);
+    for (int i = J + 1; i < QP_SEL; ++i) dt[i & 3] = fma(x[i], y[i], dt[i & 3]);
+    const double dot = (dt[0] + dt[1]) + (dt[2] + dt[3]);
     const double cf = -scale * tau * fma(scale, dot, y[J]);          // y_i -= v_i * tau * (v^T y), v_i = x_i * scale
 #pragma unroll
-    for (int i = J + 1; i < QP_SR; ++i) y[i] = fma(x[i], cf, y[i]);
+    for (int i = J + 1; i < QP_SEL; ++i) y[i] = fma(x[i], cf, y[i]);
     if (col == pcol) live = false;
     if (lane == 0 && wave == 0) sh.sel[J] = pcol;
 }
@@ -183,7 +197,7 @@ __device__ __forceinline__ void panel_step(double (&a)[16], double (&trow)[QP_B]
         if (g == 0) sh.part[par][c][wave] = part;
         if (isdiag) sh.prow[par][c] = a[J];
     } else if (g == 0) sh.part[par][c][wave] = 0.0;
-    __syncthreads();
+    lds_barrier();
     double s_c = sh.part[par][c][0], s_j = sh.part[par][J][0];
 #pragma unroll
     for (int q = 1; q < NW; ++q) { s_c += sh.part[par][c][q]; s_j += sh.part[par][J][q]; }
@@ -237,9 +251,9 @@ __global__ __launch_bounds__(64 * NW) void qp_panel_kernel(Mat Am, QrWork w, int
     {
         const int col = t;
         bool live = col < n && pivpos[col] < 0;
-        double y[QP_SR];
+        double y[QP_SEL];
 #pragma unroll
-        for (int i = 0; i < QP_SR; ++i) y[i] = col < n ? Y[(long)i * n + col] : 0.0;
+        for (int i = 0; i < QP_SEL; ++i) y[i] = col < n ? Y[(long)i * n + col] : 0.0;
 #define QP_SEL(J) select_step<J, NW>(y, live, col, lane, wave, sh);
         QP_SEL(0) QP_SEL(1) QP_SEL(2) QP_SEL(3) QP_SEL(4) QP_SEL(5) QP_SEL(6) QP_SEL(7)
         QP_SEL(8) QP_SEL(9) QP_SEL(10) QP_SEL(11) QP_SEL(12) QP_SEL(13) QP_SEL(14) QP_SEL(15)
@@ -287,11 +301,16 @@ __global__ __launch_bounds__(64 * NW) void qp_panel_kernel(Mat Am, QrWork w, int
     }
 }
 
-// grid.x = n / 16 column blocks.  UPDATE: A[k:, cols] <- (I - V T V^T)^T A[k:, cols] for the live columns of the block, then the
-// sketch of rows >= k + 16 of the result; !UPDATE (before the first panel): pivpos = -1 and the sketch of A itself.
-template <bool UPDATE>
-__global__ __launch_bounds__(256) void qp_update_kernel(Mat Am, QrWork w, int n, int k) {
-    __shared__ double red[4][QP_SR / 16 * 4][64];                // per wave partial tiles (W: 4 registers, Y: 8 registers)
+// grid.x = n / 16 column blocks, QP_UW waves each.  UPDATE: A[k:, cols] <- (I - V T V^T)^T A[k:, cols] for the live columns of the block, then
+// the sketch of rows >= k + 16 of the result; !UPDATE (before the first panel): pivpos = -1 and the sketch of A itself.
+// A wave keeps its row tiles (tile rt = wave + QP_UW ti, ti < TPW) in registers in the accumulator layout from the first load on: the same
+// registers are the B operand of W = V^T A (k-step s <-> row kk + 4 s of the tile: any partition of k works as long as V is fed the same
+// way), the accumulator of A - V W', and the B operand of the sketch product.
+constexpr int QP_UW = 8;
+template <bool UPDATE, int TPW>
+__global__ __launch_bounds__(64 * QP_UW) void qp_update_kernel(Mat Am, QrWork w, int n, int k) {
+    constexpr int YT = QP_SR / 16;
+    __shared__ double red[QP_UW][YT * 4][64];                  // per wave partial tiles (W: 4 registers, Y: 4 YT registers)
     const int chain = blockIdx.y;
     double* __restrict__ A = Am.at(chain);
     double* __restrict__ pw = w.pw + (long)chain * w.pw_stride;
@@ -302,72 +321,96 @@ __global__ __launch_bounds__(256) void qp_update_kernel(Mat Am, QrWork w, int n,
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int r16 = lane & 15, kk = lane >> 4;
     const int col = 16 * blockIdx.x + r16;
-    bool live_col = true;
-    if (UPDATE) {
-        live_col = pivpos[col] < 0;
-        if (__ballot(live_col) == 0ULL) return;                  // every wave sees the same 16 columns: a uniform exit
-    } else if (t < 16) pivpos[col] = -1;
     double* __restrict__ Ac = A + (long)n * col;
     const int m_tiles = (n - k) / 16;
+    // every global load of the launch is issued here, before the first use: the operands were written by the previous kernel (another
+    // CU, mostly another XCD), so each dependent round of loads costs a cold miss (~2 us) -- one round instead of three
+    int pp = -1;
+    if (UPDATE) pp = pivpos[col];
+    d4 At[TPW]; double v1[TPW][4], v2[TPW][4], tv[4];
+#pragma unroll
+    for (int ti = 0; ti < TPW; ++ti) {
+        const int rt = wave + QP_UW * ti;
+        At[ti] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) { v1[ti][s] = 0.0; v2[ti][s] = 0.0; }
+        if (rt < m_tiles) {
+            const int r0 = k + 16 * rt;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) At[ti][r] = Ac[r0 + kk + 4 * r];
+            if (UPDATE) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) { v1[ti][s] = Vp[(long)n * r16 + (r0 + kk + 4 * s)]; v2[ti][s] = -Vp[(long)n * (kk + 4 * s) + (r0 + r16)]; }
+            }
+        }
+    }
+    if (UPDATE) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) tv[s] = Tm[(kk + 4 * s) + QP_B * r16];
+    }
+    const bool live_col = pp < 0;
+    if (UPDATE) { if (__ballot(live_col) == 0ULL) return; }   // every wave sees the same 16 columns: a uniform exit
+    else if (t < 16) pivpos[col] = -1;
     d4 wp = {0.0, 0.0, 0.0, 0.0};
     if (UPDATE) {
-        // W = V^T A_blk: K = rows k .. n-1, split over the four waves; lane (x, kk) feeds rows base + 4 kk + s to k-step s
         d4 acc = {0.0, 0.0, 0.0, 0.0};
-        for (int rt = wave; rt < m_tiles; rt += 4) {
-            const int rb = k + 16 * rt + 4 * kk;
-            const double* vsrc = Vp + (long)n * r16 + rb;
-            const double* asrc = Ac + rb;
-            double av[4], bv[4];
 #pragma unroll
-            for (int s = 0; s < 4; ++s) { av[s] = vsrc[s]; bv[s] = asrc[s]; }
+        for (int ti = 0; ti < TPW; ++ti) {
 #pragma unroll
-            for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s], bv[s], acc, 0, 0, 0);
+            for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v1[ti][s], At[ti][s], acc, 0, 0, 0);     // tiles beyond the matrix hold zeros
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) red[wave][r][lane] = acc[r];
         __syncthreads();
         d4 W;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) W[r] = live_col ? (red[0][r][lane] + red[1][r][lane]) + (red[2][r][lane] + red[3][r][lane]) : 0.0;
+        for (int r = 0; r < 4; ++r) {
+            double v = red[0][r][lane];
+#pragma unroll
+            for (int q = 1; q < QP_UW; ++q) v += red[q][r][lane];
+            W[r] = live_col ? v : 0.0;
+        }
         // W' = T^T W: a = T[i = kk + 4 s][i' = r16], b = W[kk + 4 s][c] (the accumulator registers as they are)
 #pragma unroll
-        for (int s = 0; s < 4; ++s) wp = __builtin_amdgcn_mfma_f64_16x16x4f64(Tm[(kk + 4 * s) + QP_B * r16], W[s], wp, 0, 0, 0);
+        for (int s = 0; s < 4; ++s) wp = __builtin_amdgcn_mfma_f64_16x16x4f64(tv[s], W[s], wp, 0, 0, 0);
         __syncthreads();
     }
-    d4 ya[QP_SR / 16];
+    d4 ya[YT];
 #pragma unroll
-    for (int yt = 0; yt < QP_SR / 16; ++yt) ya[yt] = d4{0.0, 0.0, 0.0, 0.0};
-    for (int rt = wave; rt < m_tiles; rt += 4) {
-        const int r0 = k + 16 * rt;
-        d4 acc;
+    for (int yt = 0; yt < YT; ++yt) ya[yt] = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r] = Ac[r0 + kk + 4 * r];
-        if (UPDATE) {
-            const double* vsrc = Vp + r0 + r16;
+    for (int ti = 0; ti < TPW; ++ti) {
+        const int rt = wave + QP_UW * ti;
+        if (rt < m_tiles) {
+            const int r0 = k + 16 * rt;
+            if (UPDATE) {
 #pragma unroll
-            for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-vsrc[(long)n * (kk + 4 * s)], wp[s], acc, 0, 0, 0);
-            if (live_col) {
+                for (int s = 0; s < 4; ++s) At[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(v2[ti][s], wp[s], At[ti], 0, 0, 0);
+                if (live_col) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) Ac[r0 + kk + 4 * r] = acc[r];
+                    for (int r = 0; r < 4; ++r) Ac[r0 + kk + 4 * r] = At[ti][r];
+                }
             }
-        }
-        if (!UPDATE || rt >= 1) {                                  // rows of the NEXT trailing matrix: sketch them while they are in registers
+            if (!UPDATE || rt >= 1) {                              // rows of the NEXT trailing matrix: sketch them while they are in registers
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const unsigned bits = qp_row_bits((unsigned)(r0 + kk + 4 * s));
+                for (int s = 0; s < 4; ++s) {
+                    const unsigned bits = qp_row_bits((unsigned)(r0 + kk + 4 * s));
 #pragma unroll
-                for (int yt = 0; yt < QP_SR / 16; ++yt) ya[yt] = __builtin_amdgcn_mfma_f64_16x16x4f64(qp_sign(bits, 16 * yt + r16), acc[s], ya[yt], 0, 0, 0);
+                    for (int yt = 0; yt < YT; ++yt) ya[yt] = __builtin_amdgcn_mfma_f64_16x16x4f64(qp_sign(bits, 16 * yt + r16), At[ti][s], ya[yt], 0, 0, 0);
+                }
             }
         }
     }
 #pragma unroll
-    for (int yt = 0; yt < QP_SR / 16; ++yt)
+    for (int yt = 0; yt < YT; ++yt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) red[wave][4 * yt + r][lane] = ya[yt][r];
     __syncthreads();
-    for (int idx = t; idx < QP_SR / 16 * 4 * 64; idx += 256) {
+    for (int idx = t; idx < YT * 4 * 64; idx += 64 * QP_UW) {
         const int l = idx & 63, q = idx >> 6, yt = q >> 2, r = q & 3;
-        const double v = (red[0][q][l] + red[1][q][l]) + (red[2][q][l] + red[3][q][l]);
+        double v = red[0][q][l];
+#pragma unroll
+        for (int qq = 1; qq < QP_UW; ++qq) v += red[qq][q][l];
         Y[(long)(16 * yt + (l >> 4) + 4 * r) * n + 16 * blockIdx.x + (l & 15)] = v;
     }
 }
@@ -379,14 +422,19 @@ int launch_qr_panel(Mat A, QrWork w, int n, int n_chains, hipStream_t s) {
     if (!qr_panel_ok(n, w)) { set_error("panel QR: n must be a multiple of 16 in [16, 1024] and the workspace present"); return -1; }
     const dim3 ugrid(n / 16, n_chains);
     const int nw = (n + 63) / 64;
-    hipLaunchKernelGGL((qp_update_kernel<false>), ugrid, dim3(256), 0, s, A, w, n, 0);
+    const int tpw = (n / 16 + QP_UW - 1) / QP_UW;
+#define QP_UPD(U, K) do { if (tpw <= 2) hipLaunchKernelGGL((qp_update_kernel<U, 2>), ugrid, dim3(64 * QP_UW), 0, s, A, w, n, K); \
+                          else if (tpw <= 5) hipLaunchKernelGGL((qp_update_kernel<U, 5>), ugrid, dim3(64 * QP_UW), 0, s, A, w, n, K); \
+                          else hipLaunchKernelGGL((qp_update_kernel<U, 8>), ugrid, dim3(64 * QP_UW), 0, s, A, w, n, K); } while (0)
+    QP_UPD(false, 0);
     for (int k = 0; k < n; k += QP_B) {
 #define QP_LAUNCH(NW) hipLaunchKernelGGL((qp_panel_kernel<NW>), dim3(1, n_chains), dim3(64 * NW), 0, s, A, w, n, k)
         if (nw <= 1) QP_LAUNCH(1); else if (nw <= 2) QP_LAUNCH(2); else if (nw <= 4) QP_LAUNCH(4); else if (nw <= 8) QP_LAUNCH(8);
         else if (nw <= 10) QP_LAUNCH(10); else QP_LAUNCH(16);
 #undef QP_LAUNCH
-        if (k + QP_B < n) hipLaunchKernelGGL((qp_update_kernel<true>), ugrid, dim3(256), 0, s, A, w, n, k);
+        if (k + QP_B < n) QP_UPD(true, k);
     }
+#undef QP_UPD
     DQ_HIP(hipGetLastError());
     return 0;
 }

@@ -257,6 +257,14 @@ int dqmc_host_pt_get(void* p, int rank, int64_t* fields, double* G, double* logd
 }
 // DQMC::max_err() of one replica (the largest wrap-vs-stabilised difference since its engine was created)
 double dqmc_host_pt_max_err(void* p, int rank) { try { return static_cast<PtWorld*>(p)->reps.at(rank)->sim.max_err(); } catch (...) { return -1.0; } }
+// dqmc_debug_snapshot + dqmc_slice_path of one replica's engine (scripts/pt_stress.py dumps them when two worlds disagree)
+int dqmc_host_pt_debug(void* p, int rank, double* wrap_err, int* accepted, unsigned int* sync_words, unsigned int* slice_epoch, int* slice_path) {
+    try {
+        dqmc_engine* e = static_cast<PtWorld*>(p)->reps.at(rank)->sim.handle();
+        if (slice_path) *slice_path = dqmc_slice_path(e);
+        return dqmc_debug_snapshot(e, wrap_err, accepted, sync_words, slice_epoch);
+    } catch (...) { return -1; }
+}
 // the raw generator of a replica: lets a test advance a twin utility::random in lock-step
 unsigned int dqmc_host_pt_rng_peek(void* p, int rank) { std::mt19937 g = static_cast<PtWorld*>(p)->reps.at(rank)->rng.get_generator(); return g(); }
 

@@ -333,6 +333,13 @@ int dqmc_update_kernel_time(dqmc_engine* e, double* ms, int64_t* n_launches, int
  * untouched and reported DQMC_ENUMERIC (n > 256).  The paths sum the low-rank corrections in different orders: G between
  * stabilisations agrees to ~1e-11, everything after a stabilisation bitwise.  No counterpart.                        */
 int dqmc_slice_path(dqmc_engine* e);
+/* Diagnostic snapshot of chain 0 for stress tooling (scripts/pt_stress.py: when two runs of one sweep disagree, ONE event must
+ * be enough to analyse).  wrap_err[n_stack]: max|G_wrapped - G_stabilised| of every stabilisation of the LAST half sweep in
+ * the order they were taken (source/dqmc.cpp:317-329 keeps only the running maximum); accepted[nt]: accepted flips of every
+ * time slice of the last half sweep; sync_words[80]: the hand-off record of the persistent slice kernel as 32-bit words
+ * (seq lo, seq hi, error, solo_count, 12 pad, arrive[0..63]); *slice_epoch: launches of that kernel so far.  Any pointer may be
+ * NULL.  Synchronises the engine's stream.  No counterpart.                                                              */
+int dqmc_debug_snapshot(dqmc_engine* e, double* wrap_err, int* accepted, unsigned int* sync_words, unsigned int* slice_epoch);
 /* enable (1) / disable (0) the per-slice HIP-event timing above (default 0:
  * events serialise nothing but cost a few microseconds per slice).           */
 int dqmc_set_profiling(dqmc_engine* e, int on);

@@ -137,6 +137,75 @@ def qr_sketch(M, b=32, p=8, local_pivot=True, sign=False):
     return _finish(A, k, perm, Qs)
 
 
+def _house_apply(Yw, j, p):
+    """One Householder step of the sketch QR: pivot column p of the working sketch Yw (rows j..), reflector applied to all columns."""
+    x = Yw[j:, p].copy()
+    alpha = x[0]; t2 = float(x[1:] @ x[1:])
+    if t2 == 0.0:
+        return
+    beta = -np.copysign(np.sqrt(alpha * alpha + t2), alpha)
+    v = x / (alpha - beta); v[0] = 1.0
+    tau = (beta - alpha) / beta
+    Yw[j:, :] -= tau * np.outer(v, v @ Yw[j:, :])
+
+
+def qr_sketch_lookahead(M, b=16, sr=48, stats=None):
+    """qr_sketch with the selection taken OFF the critical path: the pivots of panel k + 1 are chosen from the sketch of the matrix
+    BEFORE panel k's update -- Y_k = Omega . A_k is fresh, the b known pivots of panel k are eliminated from it first (forced steps),
+    and b greedy steps on the remaining sr - b rows pick panel k + 1 (Duersch & Gu: the residual block of the sketch after b
+    Householder steps is itself a sketch of the updated trailing matrix).  On the device the selection of panel k + 1 then runs beside
+    panel k's Householder factorisation instead of in front of it (dqmc_amd/csrc/qr_panel.hip)."""
+    A = np.array(M, dtype=np.float64, copy=True)
+    n = A.shape[0]
+    perm = list(range(n)); Qs = []
+    Om = omega_sign(min(sr, 32), n) if sr <= 32 else np.vstack([omega_sign(32, n), omega_sign2(sr - 32, n)])
+    k = 0
+    nxt = None                      # original column indices chosen for the coming panel
+    while k < n:
+        nc = n - k
+        bb = min(b, nc)
+        Y = Om[:, k:] @ A[k:, k:]
+        cols = perm[k:]
+        if nxt is None:             # first panel: greedy on the fresh sketch
+            Yw = Y.copy(); live = np.ones(nc, bool); cur = []
+            for j in range(bb):
+                nr = np.where(live, np.einsum("ij,ij->j", Yw[j:], Yw[j:]), -1.0)
+                p = int(np.argmax(nr)); cur.append(p); live[p] = False
+                _house_apply(Yw, j, p)
+        else:
+            cur = [cols.index(c) for c in nxt]
+            Yw = Y.copy(); live = np.ones(nc, bool)
+            for j, p in enumerate(cur):
+                live[p] = False
+                _house_apply(Yw, j, p)
+        # greedy continuation: the pivots of the NEXT panel
+        nb2 = min(b, nc - bb)
+        nx = []
+        for j in range(bb, bb + nb2):
+            nr = np.where(live, np.einsum("ij,ij->j", Yw[j:], Yw[j:]), -1.0)
+            p = int(np.argmax(nr)); nx.append(p); live[p] = False
+            _house_apply(Yw, j, p)
+        nxt = [cols[p] for p in nx] if nx else None
+        _apply_panel(A, k, bb, perm, cur, Qs, False)
+        k += bb
+    return _finish(A, k, perm, Qs)
+
+
+def omega_sign2(rows, n):
+    """Sketch rows 32 .. 63: the bits of a second mix of the row index (qp_row_bits2 of qr_panel.hip)."""
+    assert rows <= 32
+    key = (rows, n, "sign2")
+    if key not in _OMEGA:
+        M32 = np.uint64(0xFFFFFFFF)
+        h = (np.arange(n, dtype=np.uint64) * np.uint64(0x7FEB352D) + np.uint64(0x846CA68B)) & M32
+        h ^= h >> np.uint64(16); h = (h * np.uint64(0x85EBCA6B)) & M32
+        h ^= h >> np.uint64(13); h = (h * np.uint64(0xC2B2AE35)) & M32
+        h ^= h >> np.uint64(16)
+        bits = (h[None, :] >> np.arange(rows, dtype=np.uint64)[:, None]) & np.uint64(1)
+        _OMEGA[key] = np.where(bits == 1, -1.0, 1.0)
+    return _OMEGA[key]
+
+
 def qr_normpanel(M, b=32):
     A = np.array(M, dtype=np.float64, copy=True)
     n = A.shape[0]

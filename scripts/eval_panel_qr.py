@@ -44,6 +44,9 @@ VARIANTS = {
     "sign_b16_p16_nolocal": lambda M: pq.qr_sketch(M, 16, 16, local_pivot=False, sign=True),
     "sign_b32_p16_nolocal": lambda M: pq.qr_sketch(M, 32, 16, local_pivot=False, sign=True),
     "sign_b32_p32_nolocal": lambda M: pq.qr_sketch(M, 32, 32, local_pivot=False, sign=True),
+    "lookahead_b16_sr48": lambda M: pq.qr_sketch_lookahead(M, 16, 48),
+    "lookahead_b16_sr40": lambda M: pq.qr_sketch_lookahead(M, 16, 40),
+    "lookahead_b16_sr64": lambda M: pq.qr_sketch_lookahead(M, 16, 64),
     "normpanel_b32": lambda M: pq.qr_normpanel(M, 32),
     "normpanel_b16": lambda M: pq.qr_normpanel(M, 16),
 }

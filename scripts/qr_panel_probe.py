@@ -7,7 +7,7 @@ sys.path.insert(0, ROOT)
 from dqmc_amd.abi import DqmcLib
 from oracle import panel_qr as pq
 
-lib = DqmcLib(os.path.join(ROOT, "dqmc_amd", "libdqmc_hip.so"), "dqmc_")
+lib = DqmcLib(os.environ.get("DQMC_LIB", os.path.join(ROOT, "dqmc_amd", "libdqmc_hip.so")), "dqmc_")
 sizes = [int(a) for a in sys.argv[1:]] or [64, 128, 256, 576]
 mode = "column-pivoted" if os.environ.get("DQMC_QR_PANEL") == "0" else "panel"
 for n in sizes:

@@ -42,6 +42,8 @@ def load_host():
     h.dqmc_host_pt_rng_peek.restype = C.c_uint; h.dqmc_host_pt_rng_peek.argtypes = [C.c_void_p, C.c_int]
     h.dqmc_host_hub_selftest.argtypes = [C.c_int, C.c_int]
     h.dqmc_host_pt_max_err.restype = C.c_double; h.dqmc_host_pt_max_err.argtypes = [C.c_void_p, C.c_int]
+    if hasattr(h, "dqmc_host_pt_debug"):
+        h.dqmc_host_pt_debug.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5
     return h
 
 
@@ -72,6 +74,14 @@ class HostPT:
     def set_fields(self, rank: int, fields):     # fields (nt, n)
         f = np.ascontiguousarray(np.asarray(fields).T, np.int64)              # nt x nv column-major
         self._ck(self.h.dqmc_host_pt_set_fields(self.p, rank, f.ctypes.data, self.err, 512))
+
+    def debug(self, rank: int, n_stack: int, nt: int):
+        """dqmc_debug_snapshot + dqmc_slice_path of one replica's engine: wrap errors per stabilisation and accepted flips per slice of the
+        LAST half sweep, the persistent slice kernel's hand-off words, its launch count, the slice path."""
+        we = np.zeros(n_stack); acc = np.zeros(nt, np.int32); sw = np.zeros(80, np.uint32); ep = C.c_uint(0); path = C.c_int(-1)
+        rc = self.h.dqmc_host_pt_debug(self.p, rank, we.ctypes.data, acc.ctypes.data, sw.ctypes.data, C.byref(ep), C.byref(path))
+        return dict(rc=rc, wrap_err=we, accepted=acc, seq=int(sw[0]) | (int(sw[1]) << 32), error=int(sw[2]), solo_count=int(sw[3]), arrive=sw[16:80].copy(),
+                    slice_epoch=int(ep.value), slice_path=int(path.value))
 
     def sweeps(self, n: int, concurrently: bool = True):
         self._ck(self.h.dqmc_host_pt_sweeps(self.p, n, int(concurrently), self.err, 512))

@@ -873,6 +873,25 @@ def test_persistent_submatrix_kernel_abandons_the_rest_of_a_sweep_when_the_grid_
     e.close()
 
 
+def test_debug_snapshot_matches_the_stats(hip, orc):
+    """dqmc_debug_snapshot (the record scripts/pt_stress.py dumps when two worlds disagree): per-stabilisation wrap errors and per-slice
+    accepted counts of the LAST half sweep against the folded stats and the oracle's counts; the hand-off words carry this engine's epoch."""
+    m = HubbardModel(**CONFIGS["cfg2"]); rng = np.random.default_rng(81)
+    f0 = m.random_fields(9); sf, sb = m.random_stream(rng), m.random_stream(rng)
+    e = m.engine(hip); o = m.engine(orc)
+    for x in (e, o):
+        x.set_fields(f0); x.init(); x.sweep_0_to_beta(*sf)
+    acc_f = e.stats().n_accepted
+    for x in (e, o):
+        x.sweep_beta_to_0(*sb)
+    d = e.debug_snapshot(); st = e.stats()
+    assert d["accepted"].sum() == st.n_accepted - acc_f == o.stats().n_accepted - acc_f
+    assert len(d["wrap_err"]) == m.n_stack and 0.0 < d["wrap_err"].max() <= st.max_err
+    if e.slice_path() >= 1:
+        assert d["slice_epoch"] == 2 * m.nt and (int(d["sync_words"][1]) >> 8) == d["slice_epoch"] & 0xffffff      # seq's tag = (epoch << 8) | window
+    e.close()
+
+
 def test_error_codes(hip):
     from dqmc_amd import DqmcError
     m = HubbardModel(**CONFIGS["cfg1"]); e = m.engine(hip); e.set_fields(m.random_fields(1))
