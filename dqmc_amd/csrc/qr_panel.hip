@@ -136,22 +136,35 @@ __device__ __forceinline__ void lds_barrier() {
 }
 
 // ---- selection: step J of the column-pivoted QR of the sketch ----
-template <int J, int NW>
-__device__ __forceinline__ void select_step(double (&y)[QP_SEL], bool& live, int col, int lane, int wave, PanelShared<NW>& sh) {
+// A lane owns CPL columns, col_q = t + 64 NW q (q < CPL), each as QP_SEL registers: the workgroup stays at one wave per SIMD up to
+// n = 1024 (NW = 4, CPL = 4).  With one column per lane n = 576 needs 9-10 waves, three on a SIMD, and a step costs what the three
+// issue one after the other (44.3 us per panel against the figure in DESIGN for 3 waves x 3 columns).
+template <int J, int NW, int CPL>
+__device__ __forceinline__ void select_step(double (&y)[CPL][QP_SEL], unsigned& live, int t, int lane, int wave, PanelShared<NW>& sh) {
     constexpr int par = J & 1;
-    double tl[4] = {0.0, 0.0, 0.0, 0.0};                             // four chains: a dependent fp64 FMA every ~8 clk, an independent one every 4
+    unsigned long long key = 0ULL; int bq = 0; double btail = 0.0;
 #pragma unroll
-    for (int i = J + 1; i < QP_SEL; ++i) tl[i & 3] = fma(y[i], y[i], tl[i & 3]);
-    const double tail = (tl[0] + tl[1]) + (tl[2] + tl[3]);
-    const double nrm2 = fma(y[J], y[J], tail);
-    // {norm^2 with its low 11 bits dropped | 1024 - column}: one wave maximum decides, the lowest column wins a tie
-    const unsigned long long key = live ? (((unsigned long long)__double_as_longlong(nrm2) & ~0x7FFULL) | (unsigned long long)(1024 - col)) : 0ULL;
+    for (int q = 0; q < CPL; ++q) {
+        double tl[4] = {0.0, 0.0, 0.0, 0.0};                         // four chains: a dependent fp64 FMA every ~8 clk, an independent one every 4
+#pragma unroll
+        for (int i = J + 1; i < QP_SEL; ++i) tl[i & 3] = fma(y[q][i], y[q][i], tl[i & 3]);
+        const double tail = (tl[0] + tl[1]) + (tl[2] + tl[3]);
+        const double nrm2 = fma(y[q][J], y[q][J], tail);
+        // {norm^2 with its low 11 bits dropped | 1024 - column}: one maximum decides, the lowest column wins a tie
+        const unsigned long long kq = ((live >> q) & 1u) ? (((unsigned long long)__double_as_longlong(nrm2) & ~0x7FFULL) | (unsigned long long)(1024 - (t + 64 * NW * q))) : 0ULL;
+        if (kq > key) { key = kq; bq = q; btail = tail; }
+    }
     const unsigned long long wmax = wave_max_u64(key);
     if (wmax != 0ULL && key == wmax) {          // this wave's candidate publishes BEFORE the winner among the waves is known
         sh.key[par][wave] = wmax;
 #pragma unroll
-        for (int i = J & ~1; i < QP_SEL; i += 2) *reinterpret_cast<double2*>(&sh.cand[par][wave][i]) = double2{y[i], y[i + 1]};
-        sh.cand[par][wave][QP_SEL] = tail;
+        for (int q = 0; q < CPL; ++q) {
+            if (bq == q) {
+#pragma unroll
+                for (int i = J & ~1; i < QP_SEL; i += 2) *reinterpret_cast<double2*>(&sh.cand[par][wave][i]) = double2{y[q][i], y[q][i + 1]};
+            }
+        }
+        sh.cand[par][wave][QP_SEL] = btail;
     }
     if (wmax == 0ULL && lane == 0) sh.key[par][wave] = 0ULL;
     lds_barrier();
@@ -165,37 +178,49 @@ __device__ __forceinline__ void select_step(double (&y)[QP_SEL], bool& live, int
     for (int i = J & ~1; i < QP_SEL; i += 2) { const double2 v = *reinterpret_cast<const double2*>(&xs[i]); x[i] = v.x; x[i + 1] = v.y; }
     double beta, tau, scale;
     householder<1>(x[J], xs[QP_SEL], beta, tau, scale);
-    double dt[4] = {0.0, 0.0, 0.0, 0.0};
+    const double st = -scale * tau;
 #pragma unroll
-    for (int i = J + 1; i < QP_SEL; ++i) dt[i & 3] = fma(x[i], y[i], dt[i & 3]);
-    const double dot = (dt[0] + dt[1]) + (dt[2] + dt[3]);
-    const double cf = -scale * tau * fma(scale, dot, y[J]);          // y_i -= v_i * tau * (v^T y), v_i = x_i * scale
+    for (int q = 0; q < CPL; ++q) {
+        double dt[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int i = J + 1; i < QP_SEL; ++i) y[i] = fma(x[i], cf, y[i]);
-    if (col == pcol) live = false;
+        for (int i = J + 1; i < QP_SEL; ++i) dt[i & 3] = fma(x[i], y[q][i], dt[i & 3]);
+        const double dot = (dt[0] + dt[1]) + (dt[2] + dt[3]);
+        const double cf = st * fma(scale, dot, y[q][J]);             // y_i -= v_i * tau * (v^T y), v_i = x_i * scale
+#pragma unroll
+        for (int i = J + 1; i < QP_SEL; ++i) y[q][i] = fma(x[i], cf, y[q][i]);
+        if (t + 64 * NW * q == pcol) live &= ~(1u << q);
+    }
     if (lane == 0 && wave == 0) sh.sel[J] = pcol;
 }
 
 // ---- panel: Householder step J on the 16 selected columns ----
-// a[16]: rows 64 wave + 16 g + idx of column sel[c]; isdiag: this lane's rows are the panel's own rows k .. k + 15; rows above the
-// panel (r < k) hold zeros.  x = column J below row k + J: all sources are the registers a[] themselves (row_newbcast:J picks lane J of
-// the 16-lane row); the rows <= k + J of the diagonal block are kept out by summing them separately (dots) / by a zero factor (update).
+// a[b][16]: rows 64 NW b + 64 wave + 16 g + idx of column sel[c] (b < CPL: a lane owns one 16-row block in each "layer" of 64 NW rows);
+// diag bit b: that block is the panel's own rows k .. k + 15; rows above the panel (r < k) hold zeros.  x = column J below row k + J:
+// all sources are the registers a[][] themselves (row_newbcast:J picks lane J of the 16-lane row); the rows <= k + J of the diagonal
+// block are kept out by summing them separately (dots) / by a zero factor (update).
 // The reflector tails stay UNSCALED in the registers (v_c = x_c * myscale below the diagonal, myscale kept by the lanes of column c,
 // applied at the write-out): no per-step scaling pass, and v_c^T v_J = myscale_c (x_c[k+J] + scale_J x_c^T x_J) comes out of the same dots.
-template <int J, int NW>
-__device__ __forceinline__ void panel_step(double (&a)[16], double (&trow)[QP_B], double& myscale, bool isdiag, bool wave_live, int c, int g, int wave,
+template <int J, int NW, int CPL>
+__device__ __forceinline__ void panel_step(double (&a)[CPL][16], double (&trow)[QP_B], double& myscale, unsigned diag, unsigned blk_live, int c, int g, int wave,
                                            PanelShared<NW>& sh, double* tau_out) {
     constexpr int par = J & 1;
-    if (wave_live) {
-        double dlo0 = 0.0, dlo1 = 0.0, dhi0 = 0.0, dhi1 = 0.0;
+    if (blk_live) {
+        double acc = 0.0;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            if (i <= J) { if (i & 1) dpp_fmac_self<J>(dlo1, a[i]); else dpp_fmac_self<J>(dlo0, a[i]); }
-            else { if (i & 1) dpp_fmac_self<J>(dhi1, a[i]); else dpp_fmac_self<J>(dhi0, a[i]); }
+        for (int b = 0; b < CPL; ++b) {
+            if ((blk_live >> b) & 1u) {                                // wave-uniform: blocks above the panel are skipped
+                double dlo0 = 0.0, dlo1 = 0.0, dhi0 = 0.0, dhi1 = 0.0;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    if (i <= J) { if (i & 1) dpp_fmac_self<J>(dlo1, a[b][i]); else dpp_fmac_self<J>(dlo0, a[b][i]); }
+                    else { if (i & 1) dpp_fmac_self<J>(dhi1, a[b][i]); else dpp_fmac_self<J>(dhi0, a[b][i]); }
+                }
+                acc += (dhi0 + dhi1) + (((diag >> b) & 1u) ? 0.0 : dlo0 + dlo1);
+                if ((diag >> b) & 1u) sh.prow[par][c] = a[b][J];
+            }
         }
-        const double part = rows4_sum((dhi0 + dhi1) + (isdiag ? 0.0 : dlo0 + dlo1));
+        const double part = rows4_sum(acc);
         if (g == 0) sh.part[par][c][wave] = part;
-        if (isdiag) sh.prow[par][c] = a[J];
     } else if (g == 0) sh.part[par][c][wave] = 0.0;
     lds_barrier();
     double s_c = sh.part[par][c][0], s_j = sh.part[par][J][0];
@@ -206,17 +231,23 @@ __device__ __forceinline__ void panel_step(double (&a)[16], double (&trow)[QP_B]
     householder<2>(alpha, s_j, beta, tau, scale);
     const double zc = fma(scale, s_c, apc);                           // c > J: v_J^T a_c; c < J: v_J^T x_c (x_c = the unscaled tail of v_c)
     if (c == J) myscale = scale;
-    if (wave_live) {
+    if (blk_live) {
         const double mcf = c > J ? -scale * tau * zc : 0.0;
-        const double mlo = isdiag ? 0.0 : mcf;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            if (i <= J) dpp_axpy_self<J>(a[i], mlo);
-            else dpp_axpy_self<J>(a[i], mcf);
+        for (int b = 0; b < CPL; ++b) {
+            if ((blk_live >> b) & 1u) {
+                const bool isd = (diag >> b) & 1u;
+                const double mlo = isd ? 0.0 : mcf;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    if (i <= J) dpp_axpy_self<J>(a[b][i], mlo);
+                    else dpp_axpy_self<J>(a[b][i], mcf);
+                }
+                const double newd = c > J ? fma(-tau, zc, a[b][J]) : beta;   // row k + J: v = 1
+                a[b][J] = (isd && c >= J) ? newd : a[b][J];
+                dpp_fence(a[b]);
+            }
         }
-        const double newd = c > J ? fma(-tau, zc, a[J]) : beta;       // row k + J: v = 1
-        a[J] = (isdiag && c >= J) ? newd : a[J];
-        dpp_fence(a);
     }
     // compact WY: T[0:J, J] = -tau T[0:J, 0:J] (V^T v_J), T[J][J] = tau; lane c keeps row c of T
     if (wave == 0) {
@@ -231,9 +262,9 @@ __device__ __forceinline__ void panel_step(double (&a)[16], double (&trow)[QP_B]
 
 }  // namespace
 
-// One workgroup of NW waves per chain (NW >= n / 64: lane <-> column in the selection, 64 rows per wave in the panel): selects the
-// 16 columns of the panel that starts at step k and factors them.
-template <int NW>
+// One workgroup of NW waves per chain (64 NW CPL >= n: a lane owns CPL columns in the selection and CPL 16-row blocks of one column in
+// the panel): selects the 16 columns of the panel that starts at step k and factors them.
+template <int NW, int CPL>
 __global__ __launch_bounds__(64 * NW) void qp_panel_kernel(Mat Am, QrWork w, int n, int k) {
     __shared__ PanelShared<NW> sh;
     const int chain = blockIdx.y;
@@ -249,48 +280,59 @@ __global__ __launch_bounds__(64 * NW) void qp_panel_kernel(Mat Am, QrWork w, int
 
     // ---- selection ----
     {
-        const int col = t;
-        bool live = col < n && pivpos[col] < 0;
-        double y[QP_SEL];
+        unsigned live = 0u;
+        double y[CPL][QP_SEL];
 #pragma unroll
-        for (int i = 0; i < QP_SEL; ++i) y[i] = col < n ? Y[(long)i * n + col] : 0.0;
-#define QP_SEL(J) select_step<J, NW>(y, live, col, lane, wave, sh);
-        QP_SEL(0) QP_SEL(1) QP_SEL(2) QP_SEL(3) QP_SEL(4) QP_SEL(5) QP_SEL(6) QP_SEL(7)
-        QP_SEL(8) QP_SEL(9) QP_SEL(10) QP_SEL(11) QP_SEL(12) QP_SEL(13) QP_SEL(14) QP_SEL(15)
-#undef QP_SEL
+        for (int q = 0; q < CPL; ++q) {
+            const int col = t + 64 * NW * q;
+            if (col < n && pivpos[col] < 0) live |= 1u << q;
+#pragma unroll
+            for (int i = 0; i < QP_SEL; ++i) y[q][i] = col < n ? Y[(long)i * n + col] : 0.0;
+        }
+#define QP_SEL_STEP(J) select_step<J, NW, CPL>(y, live, t, lane, wave, sh);
+        QP_SEL_STEP(0) QP_SEL_STEP(1) QP_SEL_STEP(2) QP_SEL_STEP(3) QP_SEL_STEP(4) QP_SEL_STEP(5) QP_SEL_STEP(6) QP_SEL_STEP(7)
+        QP_SEL_STEP(8) QP_SEL_STEP(9) QP_SEL_STEP(10) QP_SEL_STEP(11) QP_SEL_STEP(12) QP_SEL_STEP(13) QP_SEL_STEP(14) QP_SEL_STEP(15)
+#undef QP_SEL_STEP
     }
-    __syncthreads();
+    lds_barrier();
     // ---- panel ----
     const int c = lane & 15, g = lane >> 4;
     const int mycol = sh.sel[c];
-    const int r0 = 64 * wave + 16 * g;
-    const bool isdiag = r0 == k;
-    const bool wave_live = 64 * wave + 64 > k && 64 * wave < n;         // a wave whose rows all lie above the panel only keeps the barriers (and T: wave 0)
-    double a[16], trow[QP_B], myscale = 0.0;
-    {
+    double a[CPL][16], trow[QP_B], myscale = 0.0;
+    unsigned diag = 0u, blk_live = 0u;
+#pragma unroll
+    for (int b = 0; b < CPL; ++b) {
+        const int r0 = 64 * NW * b + 64 * wave + 16 * g;
+        if (r0 == k) diag |= 1u << b;
+        if (64 * NW * b + 64 * wave + 64 > k && 64 * NW * b + 64 * wave < n) blk_live |= 1u << b;   // wave-uniform: some row of the wave's 64 is in the panel
         const double* src = A + (long)n * mycol + r0;
         const bool rows_live = r0 >= k && r0 < n;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) a[i] = rows_live ? src[i] : 0.0;
-#pragma unroll
-        for (int i = 0; i < QP_B; ++i) trow[i] = 0.0;
-        dpp_fence(a);
+        for (int i = 0; i < 16; ++i) a[b][i] = rows_live ? src[i] : 0.0;
+        dpp_fence(a[b]);
     }
+#pragma unroll
+    for (int i = 0; i < QP_B; ++i) trow[i] = 0.0;
     double* tau_out = tau + k;
-#define QP_PAN(J) panel_step<J, NW>(a, trow, myscale, isdiag, wave_live, c, g, wave, sh, tau_out);
+#define QP_PAN(J) panel_step<J, NW, CPL>(a, trow, myscale, diag, blk_live, c, g, wave, sh, tau_out);
     QP_PAN(0) QP_PAN(1) QP_PAN(2) QP_PAN(3) QP_PAN(4) QP_PAN(5) QP_PAN(6) QP_PAN(7)
     QP_PAN(8) QP_PAN(9) QP_PAN(10) QP_PAN(11) QP_PAN(12) QP_PAN(13) QP_PAN(14) QP_PAN(15)
 #undef QP_PAN
     // ---- write-out: R0 / beta / reflectors in place, the clean reflector panel (unit diagonal, zeros above), T, jpvt, pivpos ----
-    if (r0 >= k && r0 < n) {
-        double* dst = A + (long)n * mycol + r0;
-        double* vdst = Vp + (long)n * c + r0;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const bool below = !isdiag || i > c;                          // strictly below the column's diagonal: the reflector tail
-            const double v = below ? a[i] * myscale : a[i];
-            dst[i] = v;
-            vdst[i] = below ? v : (i == c ? 1.0 : 0.0);
+    for (int b = 0; b < CPL; ++b) {
+        const int r0 = 64 * NW * b + 64 * wave + 16 * g;
+        if (r0 >= k && r0 < n) {
+            const bool isd = (diag >> b) & 1u;
+            double* dst = A + (long)n * mycol + r0;
+            double* vdst = Vp + (long)n * c + r0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const bool below = !isd || i > c;                         // strictly below the column's diagonal: the reflector tail
+                const double v = below ? a[b][i] * myscale : a[b][i];
+                dst[i] = v;
+                vdst[i] = below ? v : (i == c ? 1.0 : 0.0);
+            }
         }
     }
     if (wave == 0 && g == 0) {
@@ -421,16 +463,15 @@ long qr_panel_work_doubles(int n) { return (long)(QP_SR + QP_B) * n + QP_B * QP_
 int launch_qr_panel(Mat A, QrWork w, int n, int n_chains, hipStream_t s) {
     if (!qr_panel_ok(n, w)) { set_error("panel QR: n must be a multiple of 16 in [16, 1024] and the workspace present"); return -1; }
     const dim3 ugrid(n / 16, n_chains);
-    const int nw = (n + 63) / 64;
     const int tpw = (n / 16 + QP_UW - 1) / QP_UW;
 #define QP_UPD(U, K) do { if (tpw <= 2) hipLaunchKernelGGL((qp_update_kernel<U, 2>), ugrid, dim3(64 * QP_UW), 0, s, A, w, n, K); \
                           else if (tpw <= 5) hipLaunchKernelGGL((qp_update_kernel<U, 5>), ugrid, dim3(64 * QP_UW), 0, s, A, w, n, K); \
                           else hipLaunchKernelGGL((qp_update_kernel<U, 8>), ugrid, dim3(64 * QP_UW), 0, s, A, w, n, K); } while (0)
     QP_UPD(false, 0);
     for (int k = 0; k < n; k += QP_B) {
-#define QP_LAUNCH(NW) hipLaunchKernelGGL((qp_panel_kernel<NW>), dim3(1, n_chains), dim3(64 * NW), 0, s, A, w, n, k)
-        if (nw <= 1) QP_LAUNCH(1); else if (nw <= 2) QP_LAUNCH(2); else if (nw <= 4) QP_LAUNCH(4); else if (nw <= 8) QP_LAUNCH(8);
-        else if (nw <= 10) QP_LAUNCH(10); else QP_LAUNCH(16);
+#define QP_LAUNCH(NW, CPL) hipLaunchKernelGGL((qp_panel_kernel<NW, CPL>), dim3(1, n_chains), dim3(64 * NW), 0, s, A, w, n, k)
+        if (n <= 64) QP_LAUNCH(1, 1); else if (n <= 128) QP_LAUNCH(2, 1); else if (n <= 256) QP_LAUNCH(4, 1); else if (n <= 512) QP_LAUNCH(4, 2);
+        else if (n <= 576) QP_LAUNCH(3, 3); else if (n <= 768) QP_LAUNCH(4, 3); else QP_LAUNCH(4, 4);
 #undef QP_LAUNCH
         if (k + QP_B < n) QP_UPD(true, k);
     }
