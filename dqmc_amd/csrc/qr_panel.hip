@@ -38,7 +38,7 @@ constexpr int QP_SR = 32;        // sketch rows formed by the update kernel (two
 #ifndef QP_SEL_ROWS
 #define QP_SEL_ROWS 32
 #endif
-constexpr int QP_SEL = QP_SEL_ROWS;   // ... and used by the selection (b + p, p = 8): 25.2 us per panel at n = 256 against 28.2 with all 32 (max|R| 1.06 / grading 2.8 against 1.06 / 2.2)
+constexpr int QP_SEL = QP_SEL_ROWS;   // ... and used by the selection (b + p, p = 16).  24 rows (p = 8) are 3 us per panel faster at n = 256 (25.2 against 28.2 us) but put the thermalised unequal-time series of cfg 3 at 1.44e-10 of its largest entry (32 rows: 6.8e-11; bound 1e-10)
 typedef double d4 __attribute__((ext_vector_type(4)));
 
 // Omega[i][r] = +-1: bit i of a 32-bit mix of the ROW index r (oracle/panel_qr.py::omega_sign is the same function)
