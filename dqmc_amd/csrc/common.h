@@ -112,12 +112,7 @@ struct QrWork {
     int* info = nullptr;                                        // |= 2 when a cooperative factorisation gave up waiting
     double* pw = nullptr; long pw_stride = 0;                   // panel-pivoted QR (qr_panel.hip): sketch, clean reflector panel, T; >= qr_panel_work_doubles(n) per chain
     int* pivpos = nullptr; long pivpos_stride = 0;              // panel-pivoted QR: pivot position of every column (-1 = live), n per chain
-    void* fsync = nullptr;                                      // fused panel QR: one SliceSync record (SLICE_SYNC_BYTES) per chain, zeroed once
-    unsigned fused_epoch = 0;                                   // ... and the launch number its tags carry (0: take the multi-launch path)
-    int debug_absent_blk = -1;                                  // debug (DQMC_DEBUG_QR_ABSENT=<block>): that update workgroup leaves at once
-    int debug_late_blk = -1, debug_late_us = 0;                 // debug (DQMC_DEBUG_QR_LATE=<block>:<us>): that update workgroup checks in late
 };
-int launch_qr_panel_fused(Mat A, QrWork w, int n, int n_chains, hipStream_t s, unsigned epoch);   // the same factorisation in ONE launch (persistent workgroups)
 long qr_panel_work_doubles(int n);
 bool qr_panel_ok(int n, const QrWork& w);   // n a multiple of 16 in [16, 1024] and the workspace present
 int launch_qr_panel(Mat A, QrWork w, int n, int n_chains, hipStream_t s);   // qr_panel.hip: A -> reflectors / R0 in place, tau, jpvt (same format as the QRCP kernels)

@@ -66,8 +66,6 @@ struct Ctx {
     double* tinv = nullptr;                    // Gauss-Jordan panel inverses: 2048 * C
     double* qpw = nullptr;                     // panel-pivoted QR (qr_panel.hip): qr_panel_work_doubles(n) * C
     int* qpivpos = nullptr;                    // ... and its pivot positions: n * C
-    void* qfsync = nullptr;                    // ... and the hand-off records of its fused single-launch form: SLICE_SYNC_BYTES * C
-    unsigned qf_epoch = 0;                     // launches of the fused panel QR so far (the tag of its hand-off words)
     double* trinv = nullptr;                   // blocked triangular solve: inverses of the 16 x 16 diagonal blocks, 16 * (n + 16) * C
     bool use_tri = false;                      // R^-1 D by tri_solve.hip (n <= 640; the per-column substitution of lu.hip above that)
     bool use_gj = false;                       // n <= 256, few chains: solves go through lu_gj.hip (DQMC_LU_CLASSIC=1 keeps dgetrf + dgetrs)
@@ -97,8 +95,6 @@ struct Ctx {
         if (n % 16 == 0 && n <= 1024) {
             DQ_HIP(hipMalloc(&qpw, sizeof(double) * qr_panel_work_doubles(n) * C));
             DQ_HIP(hipMalloc(&qpivpos, sizeof(int) * (size_t)n * C));
-            DQ_HIP(hipMalloc(&qfsync, SLICE_SYNC_BYTES * (size_t)C));
-            DQ_HIP(hipMemsetAsync(qfsync, 0, SLICE_SYNC_BYTES * (size_t)C, stream));
         }
         use_tri = n <= 640;     // any number of chains (128 chains at cfg 3: 432.9 against 437.3 ms per step)
         // latency regime only: with many chains per launch the blocked LU + per-column substitution has the higher throughput
@@ -120,7 +116,6 @@ struct Ctx {
         if (trinv) (void)hipFree(trinv);
         if (qpw) (void)hipFree(qpw);
         if (qpivpos) (void)hipFree(qpivpos);
-        if (qfsync) (void)hipFree(qfsync);
         if (stream) (void)hipStreamDestroy(stream);
     }
 
@@ -136,10 +131,6 @@ struct Ctx {
         QrWork w{V(7).p, (long)n, keep ? out.jpvt : jpvt(), (long)n};
         w.sync = qsync; w.sync_stride = qrcp_coop_sync_granules(n); w.abort_words = qabort; w.info = info();
         w.pw = qpw; w.pw_stride = qr_panel_work_doubles(n); w.pivpos = qpivpos; w.pivpos_stride = n;
-        if (qfsync) {
-            if (++qf_epoch >= SLICE_EPOCH_LIMIT) { DQ_HIP(hipMemsetAsync(qfsync, 0, SLICE_SYNC_BYTES * (size_t)C, stream)); qf_epoch = 1; }
-            w.fsync = qfsync; w.fused_epoch = qf_epoch;
-        }
         if (out.tri) *out.tri = keep;
         return launch_to_ldr(A, out.L, out.d, out.R, w, n, C, stream);
     }

@@ -26,8 +26,6 @@
 #include "common.h"
 #include "wave.h"
 #include <utility>
-#include <cstdlib>
-#include <cstring>
 
 namespace dq {
 
@@ -127,25 +125,6 @@ __device__ __forceinline__ void householder(double alpha, double tail2, double& 
     beta = none ? alpha : b;
     tau = none ? 0.0 : d * copysign(r, alpha);                         // (beta - alpha) / beta = -d / beta = d * sign(alpha) / sqrt(s)
     scale = none ? 0.0 : id;
-}
-
-// COH: agent-scope relaxed accesses (global_load / global_store ... sc1: past the CU's L1, written through) -- what the fused kernel uses
-// for every byte another workgroup of the same launch writes or reads (the slice kernels' idiom, update.hip); plain accesses otherwise
-template <bool COH> __device__ __forceinline__ double ldd(const double* p) {
-    if (COH) return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    return *p;
-}
-template <bool COH> __device__ __forceinline__ void std_(double* p, double x) {
-    if (COH) __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else *p = x;
-}
-template <bool COH> __device__ __forceinline__ int ldi(const int* p) {
-    if (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return *p;
-}
-template <bool COH> __device__ __forceinline__ void sti(int* p, int x) {
-    if (COH) __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else *p = x;
 }
 
 // the steps exchange data through LDS only: a barrier that does not drain the vector memory queue (__syncthreads() is s_waitcnt vmcnt(0)
@@ -281,14 +260,22 @@ __device__ __forceinline__ void panel_step(double (&a)[CPL][16], double (&trow)[
     }
 }
 
-// One workgroup of NW waves (64 NW CPL >= n: a lane owns CPL columns in the selection and CPL 16-row blocks of one column in the panel):
-// selects the 16 columns of the panel that starts at step k and factors them.
-template <int NW, int CPL, bool COH>
-__device__ __forceinline__ void panel_role(double* __restrict__ A, double* __restrict__ pw, int* __restrict__ pivpos, double* tau, int* jpvt, int n, int k,
-                                           PanelShared<NW>& sh) {
+}  // namespace
+
+// One workgroup of NW waves per chain (64 NW CPL >= n: a lane owns CPL columns in the selection and CPL 16-row blocks of one column in
+// the panel): selects the 16 columns of the panel that starts at step k and factors them.
+template <int NW, int CPL>
+__global__ __launch_bounds__(64 * NW) void qp_panel_kernel(Mat Am, QrWork w, int n, int k) {
+    __shared__ PanelShared<NW> sh;
+    const int chain = blockIdx.y;
+    double* __restrict__ A = Am.at(chain);
+    double* __restrict__ pw = w.pw + (long)chain * w.pw_stride;
     const double* __restrict__ Y = pw;                         // [QP_SR][n]
     double* __restrict__ Vp = pw + (long)QP_SR * n;           // [n][QP_B] column-major clean copy of the panel's reflectors
     double* __restrict__ Tm = Vp + (long)QP_B * n;            // [QP_B][QP_B] column-major
+    int* __restrict__ pivpos = w.pivpos + (long)chain * w.pivpos_stride;
+    double* tau = w.tau + (long)chain * w.tau_stride;
+    int* jpvt = w.jpvt + (long)chain * w.jpvt_stride;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
 
     // ---- selection ----
@@ -298,9 +285,9 @@ __device__ __forceinline__ void panel_role(double* __restrict__ A, double* __res
 #pragma unroll
         for (int q = 0; q < CPL; ++q) {
             const int col = t + 64 * NW * q;
-            if (col < n && ldi<COH>(pivpos + col) < 0) live |= 1u << q;
+            if (col < n && pivpos[col] < 0) live |= 1u << q;
 #pragma unroll
-            for (int i = 0; i < QP_SEL; ++i) y[q][i] = col < n ? ldd<COH>(Y + (long)i * n + col) : 0.0;
+            for (int i = 0; i < QP_SEL; ++i) y[q][i] = col < n ? Y[(long)i * n + col] : 0.0;
         }
 #define QP_SEL_STEP(J) select_step<J, NW, CPL>(y, live, t, lane, wave, sh);
         QP_SEL_STEP(0) QP_SEL_STEP(1) QP_SEL_STEP(2) QP_SEL_STEP(3) QP_SEL_STEP(4) QP_SEL_STEP(5) QP_SEL_STEP(6) QP_SEL_STEP(7)
@@ -321,7 +308,7 @@ __device__ __forceinline__ void panel_role(double* __restrict__ A, double* __res
         const double* src = A + (long)n * mycol + r0;
         const bool rows_live = r0 >= k && r0 < n;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) a[b][i] = rows_live ? ldd<COH>(src + i) : 0.0;
+        for (int i = 0; i < 16; ++i) a[b][i] = rows_live ? src[i] : 0.0;
         dpp_fence(a[b]);
     }
 #pragma unroll
@@ -343,27 +330,17 @@ __device__ __forceinline__ void panel_role(double* __restrict__ A, double* __res
             for (int i = 0; i < 16; ++i) {
                 const bool below = !isd || i > c;                         // strictly below the column's diagonal: the reflector tail
                 const double v = below ? a[b][i] * myscale : a[b][i];
-                std_<COH>(dst + i, v);
-                std_<COH>(vdst + i, below ? v : (i == c ? 1.0 : 0.0));
+                dst[i] = v;
+                vdst[i] = below ? v : (i == c ? 1.0 : 0.0);
             }
         }
     }
     if (wave == 0 && g == 0) {
 #pragma unroll
-        for (int i = 0; i < QP_B; ++i) std_<COH>(Tm + c + QP_B * i, trow[i]);
+        for (int i = 0; i < QP_B; ++i) Tm[c + QP_B * i] = trow[i];
         jpvt[k + c] = mycol;
-        sti<COH>(pivpos + mycol, k + c);
+        pivpos[mycol] = k + c;
     }
-}
-
-}  // namespace
-
-template <int NW, int CPL>
-__global__ __launch_bounds__(64 * NW) void qp_panel_kernel(Mat Am, QrWork w, int n, int k) {
-    __shared__ PanelShared<NW> sh;
-    const int chain = blockIdx.y;
-    panel_role<NW, CPL, false>(Am.at(chain), w.pw + (long)chain * w.pw_stride, w.pivpos + (long)chain * w.pivpos_stride, w.tau + (long)chain * w.tau_stride,
-                               w.jpvt + (long)chain * w.jpvt_stride, n, k, sh);
 }
 
 // grid.x = n / 16 column blocks, QP_UW waves each.  UPDATE: A[k:, cols] <- (I - V T V^T)^T A[k:, cols] for the live columns of the block, then
@@ -480,290 +457,11 @@ __global__ __launch_bounds__(64 * QP_UW) void qp_update_kernel(Mat Am, QrWork w,
     }
 }
 
-// ================= the whole factorisation in ONE launch =================
-// A dependent kernel costs ~4.5 us before it does anything (dispatch, acquire, end-of-kernel release) and its first loads miss every
-// cache (the operands were written on other CUs, mostly other XCDs): 2 launches x n / 16 panels.  The fused kernel keeps one panel
-// workgroup and n / 16 update workgroups resident for the whole factorisation and hands over through global memory exactly like the
-// persistent slice kernels (update.hip, SliceSync): payload written and read with agent-scope accesses, every storing wave drains
-// (s_waitcnt vmcnt(0)), workgroup barrier, ONE word published; tags carry the launch number, so nothing is ever re-armed.
-//   update workgroup b : check in (arrive[b] = tag(e, 0)) -> sketch of its 16 columns -> arrive[b] = tag(e, 1) ->
-//                        for p = 0 .. n/16 - 2: wait seq == tag(e, p + 1), update p + sketch, arrive[b] = tag(e, p + 2).
-//                        Its row tiles of A stay in REGISTERS for the whole launch (fixed ownership: tile rt = wave + NW ti), they are
-//                        stored after every update only because the panel workgroup may pick any column next.
-//   panel workgroup    : census (all arrive[b] == tag(e, 1) within a bounded wait, before anything but sketches has been written) ->
-//                        for p: wait arrive[] == tag(e, p + 1), select + factor panel p, seq = tag(e, p + 1).
-// Residency is checked, not assumed: if the census fails the panel workgroup publishes the SOLO word (update workgroups that are or
-// become resident leave without touching A) and runs every update itself, same arithmetic in the same order -- slower, same result.
-template <int NW, int TPW, bool KEEP>
-__device__ __forceinline__ void fused_update(d4 (&At)[TPW], double* __restrict__ A, double* __restrict__ pw, int* __restrict__ pivpos, int n, int k, int blk,
-                                             double (*red)[8][64]) {
-    constexpr int YT = QP_SR / 16;
-    double* __restrict__ Y = pw;
-    const double* __restrict__ Vp = pw + (long)QP_SR * n;
-    const double* __restrict__ Tm = Vp + (long)QP_B * n;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int r16 = lane & 15, kk = lane >> 4;
-    const int col = 16 * blk + r16;
-    double* __restrict__ Ac = A + (long)n * col;
-    const bool first = k < 0;                                    // the sketch of A itself, before the first panel
-    const int n_tiles = n / 16;
-    if (!KEEP || first) {
-#pragma unroll
-        for (int ti = 0; ti < TPW; ++ti) {
-            const int rt = wave + NW * ti;
-            At[ti] = d4{0.0, 0.0, 0.0, 0.0};
-            if (rt < n_tiles && 16 * rt >= k) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) At[ti][r] = ldd<true>(Ac + 16 * rt + kk + 4 * r);
-            }
-        }
-    }
-    bool live_col = true;
-    if (first) { if (t < 16) sti<true>(pivpos + col, -1); }
-    else live_col = ldi<true>(pivpos + col) < 0;
-    if (__ballot(live_col) == 0ULL) return;                      // every wave sees the same 16 columns: a uniform decision
-    d4 wp = {0.0, 0.0, 0.0, 0.0};
-    // every operand the panel workgroup has just published is requested in ONE round of loads (each dependent round is a trip past
-    // the L1 to wherever the other workgroup's write-through stores landed)
-    double v1[TPW][4], v2[TPW][4], tv[4];
-    if (!first) {
-#pragma unroll
-        for (int s = 0; s < 4; ++s) tv[s] = ldd<true>(Tm + (kk + 4 * s) + QP_B * r16);
-#pragma unroll
-        for (int ti = 0; ti < TPW; ++ti) {
-            const int rt = wave + NW * ti;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) { v1[ti][s] = 0.0; v2[ti][s] = 0.0; }
-            if (rt < n_tiles && 16 * rt >= k) {
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    v1[ti][s] = ldd<true>(Vp + (long)n * r16 + (16 * rt + kk + 4 * s));
-                    v2[ti][s] = -ldd<true>(Vp + (long)n * (kk + 4 * s) + (16 * rt + r16));
-                }
-            }
-        }
-        d4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int ti = 0; ti < TPW; ++ti) {
-#pragma unroll
-            for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v1[ti][s], At[ti][s], acc, 0, 0, 0);   // v1 = 0 for tiles above the panel
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) red[wave][r][lane] = acc[r];
-        __syncthreads();
-        d4 W;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            double v = red[0][r][lane];
-#pragma unroll
-            for (int q = 1; q < NW; ++q) v += red[q][r][lane];
-            W[r] = live_col ? v : 0.0;
-        }
-#pragma unroll
-        for (int s = 0; s < 4; ++s) wp = __builtin_amdgcn_mfma_f64_16x16x4f64(tv[s], W[s], wp, 0, 0, 0);
-        __syncthreads();
-    }
-    d4 ya[YT];
-#pragma unroll
-    for (int yt = 0; yt < YT; ++yt) ya[yt] = d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int ti = 0; ti < TPW; ++ti) {
-        const int rt = wave + NW * ti;
-        const int r0 = 16 * rt;
-        if (rt < n_tiles && r0 >= k) {
-            if (!first) {
-#pragma unroll
-                for (int s = 0; s < 4; ++s) At[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(v2[ti][s], wp[s], At[ti], 0, 0, 0);
-                if (live_col) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) std_<true>(Ac + r0 + kk + 4 * r, At[ti][r]);
-                }
-            }
-            if (first || r0 >= k + 16) {
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const unsigned bits = qp_row_bits((unsigned)(r0 + kk + 4 * s));
-#pragma unroll
-                    for (int yt = 0; yt < YT; ++yt) ya[yt] = __builtin_amdgcn_mfma_f64_16x16x4f64(qp_sign(bits, 16 * yt + r16), At[ti][s], ya[yt], 0, 0, 0);
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int yt = 0; yt < YT; ++yt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) red[wave][4 * yt + r][lane] = ya[yt][r];
-    __syncthreads();
-    for (int idx = t; idx < YT * 4 * 64; idx += 64 * NW) {
-        const int l = idx & 63, q = idx >> 6, yt = q >> 2, r = q & 3;
-        double v = red[0][q][l];
-#pragma unroll
-        for (int qq = 1; qq < NW; ++qq) v += red[qq][q][l];
-        std_<true>(Y + (long)(16 * yt + (l >> 4) + 4 * r) * n + 16 * blk + (l & 15), v);
-    }
-    __syncthreads();                                               // red is reused by the caller's next block / next panel
-}
-
-// the solo fall-back's updates as a real function call: inlined, its registers join the allocation problem of the kernel's hot roles
-template <int NW, int TPW>
-__device__ __attribute__((noinline)) void solo_updates(double* A, double* pw, int* pivpos, int n, int k, double (*red)[8][64]) {
-    d4 At[TPW];
-    for (int b = 0; b < n / 16; ++b) fused_update<NW, TPW, false>(At, A, pw, pivpos, n, k, b, red);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-}
-
-constexpr unsigned QF_SPIN_LIMIT = 1u << 22;      // polls (>= 1 us each) a resident partner is given
-constexpr unsigned QF_CENSUS_SPINS = 512;         // polls the panel workgroup grants the update workgroups for their first sketch (~200-400 us)
-
-template <int NW, int CPL, int TPW>
-__global__ __launch_bounds__(64 * NW) void qp_fused_kernel(Mat Am, QrWork w, int n, unsigned epoch) {
-    __shared__ PanelShared<NW> sh;
-    __shared__ double red[NW][8][64];
-    __shared__ unsigned long long bcast[2];
-    __shared__ int verdict;
-    const int chain = blockIdx.y;
-    double* __restrict__ A = Am.at(chain);
-    double* __restrict__ pw = w.pw + (long)chain * w.pw_stride;
-    int* __restrict__ pivpos = w.pivpos + (long)chain * w.pivpos_stride;
-    SliceSync* sy = reinterpret_cast<SliceSync*>(w.fsync) + chain;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int NB = n / 16;
-
-    if (blockIdx.x > 0) {
-        // ================= update role =================
-        const int b = blockIdx.x - 1;
-        if (b == w.debug_absent_blk) return;                         // debug: a workgroup that never becomes resident
-        if (b == w.debug_late_blk) {                                 // debug: a workgroup that becomes resident LATE
-            const unsigned long long t0 = wall_clock64();
-            while (wall_clock64() - t0 < 100ull * (unsigned long long)w.debug_late_us) __builtin_amdgcn_s_sleep(64);
-        }
-        if (t == 0) __hip_atomic_store(&sy->arrive[b], slice_tag(epoch, 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        {   // has the panel workgroup given up on the census already?  (a late arrival must not write Y or pivpos: the solo run owns them.)
-            // Store, drain, load here -- store, drain, load on the other side: one of the two sees the other's word
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (t == 0) { const unsigned long long w0 = __hip_atomic_load(&sy->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                          verdict = ((unsigned)(w0 >> 40) == (slice_tag(epoch, 0) >> 8) && ((unsigned)w0 & SLICE_SOLO_BIT)) ? 1 : 0; }
-            __syncthreads();
-            if (verdict) return;
-        }
-        d4 At[TPW];
-        fused_update<NW, TPW, true>(At, A, pw, pivpos, n, -16, b, red);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (t == 0) __hip_atomic_store(&sy->arrive[b], slice_tag(epoch, 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        for (int p = 0; p + 1 < NB; ++p) {
-            const unsigned win = (unsigned)p + 1;
-            if (wave == 0) {
-                unsigned long long word = 0; unsigned spins = 0; bool give_up = false;
-                for (;;) {
-                    word = __hip_atomic_load(&sy->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const unsigned tag = (unsigned)(word >> 32);
-                    if (tag == slice_tag(epoch, win)) break;
-                    if ((tag >> 8) == (slice_tag(epoch, 0) >> 8)) {   // a word of this launch for another window: solo -> leave; anything else is a protocol error
-                        if ((unsigned)word & SLICE_SOLO_BIT) break;
-                        if ((tag & 0xffu) > win) { give_up = true; break; }
-                    }
-                    if (++spins > QF_SPIN_LIMIT) { give_up = true; break; }
-                    __builtin_amdgcn_s_sleep(1);
-                }
-                if (give_up && lane == 0) { __hip_atomic_store(&sy->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (w.info) atomicOr(w.info, 2); }
-                if (lane == 0) bcast[win & 1] = give_up ? ~0ULL : word;
-            }
-            __syncthreads();
-            const unsigned long long word = bcast[win & 1];
-            if (word == ~0ULL || ((unsigned)word & SLICE_SOLO_BIT)) return;
-            fused_update<NW, TPW, true>(At, A, pw, pivpos, n, 16 * p, b, red);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains before the arrival is signalled
-            __syncthreads();
-            if (t == 0) __hip_atomic_store(&sy->arrive[b], slice_tag(epoch, win + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        return;
-    }
-    // ================= panel role =================
-    double* tau = w.tau + (long)chain * w.tau_stride;
-    int* jpvt = w.jpvt + (long)chain * w.jpvt_stride;
-    bool solo = false;
-    for (int p = 0; p < NB; ++p) {
-        // wait until every update workgroup has delivered the sketch this panel is selected from (p = 0: the census)
-        if (!solo) {
-            if (wave == 0) {
-                const unsigned want = slice_tag(epoch, (unsigned)p + 1);
-                unsigned spins = 0; int v = 0;
-                for (;;) {
-                    const unsigned a_ = lane < NB ? __hip_atomic_load(&sy->arrive[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : want;
-                    if (__all(a_ == want)) break;
-                    if (++spins > (p == 0 ? QF_CENSUS_SPINS : QF_SPIN_LIMIT)) { v = p == 0 ? 1 : 2; break; }
-                    if (p == 0) __builtin_amdgcn_s_sleep(8); else __builtin_amdgcn_s_sleep(1);
-                }
-                if (lane == 0) verdict = v;
-            }
-            __syncthreads();
-            const int v = verdict;
-            __syncthreads();
-            if (v == 2) { if (t == 0) { __hip_atomic_store(&sy->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (w.info) atomicOr(w.info, 2); } return; }
-            if (v == 1) {
-                // some update workgroup is not resident: nobody else will touch A, Y or pivpos in this launch
-                solo = true;
-                if (t == 0) {
-                    __hip_atomic_store(&sy->seq, ((unsigned long long)slice_tag(epoch, 1) << 32) | SLICE_SOLO_BIT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_fetch_add(&sy->solo_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                // a workgroup that checked in may still be inside its first sketch (it looks at seq only before and after): wait for those
-                if (wave == 0) {
-                    unsigned spins = 0;
-                    for (;;) {
-                        const unsigned a_ = lane < NB ? __hip_atomic_load(&sy->arrive[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-                        if (!__any(a_ == slice_tag(epoch, 0))) break;
-                        if (++spins > QF_SPIN_LIMIT) break;
-                        __builtin_amdgcn_s_sleep(8);
-                    }
-                }
-                __syncthreads();
-                solo_updates<NW, TPW>(A, pw, pivpos, n, -16, red);
-            }
-        }
-        panel_role<NW, CPL, true>(A, pw, pivpos, tau, jpvt, n, 16 * p, sh);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the panel's stores have left the CU
-        __syncthreads();
-        if (!solo) {
-            if (t == 0) __hip_atomic_store(&sy->seq, ((unsigned long long)slice_tag(epoch, (unsigned)p + 1) << 32) | (p + 1 == NB ? SLICE_FINAL_BIT : 0u),
-                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else if (p + 1 < NB) {
-            solo_updates<NW, TPW>(A, pw, pivpos, n, 16 * p, red);
-        }
-    }
-}
-
 bool qr_panel_ok(int n, const QrWork& w) { return n >= 16 && n <= 1024 && n % 16 == 0 && w.pw != nullptr && w.pivpos != nullptr && w.pw_stride >= qr_panel_work_doubles(n); }
 long qr_panel_work_doubles(int n) { return (long)(QP_SR + QP_B) * n + QP_B * QP_B; }
 
-// the fused single-launch form: n / 16 + 1 workgroups per chain that must be co-resident (they are, unless the device is full of
-// other work: then the census sends the launch down the solo path)
-int launch_qr_panel_fused(Mat A, QrWork w, int n, int n_chains, hipStream_t s, unsigned epoch) {
-    if (!qr_panel_ok(n, w) || !w.fsync) { set_error("fused panel QR: workspace missing"); return -1; }
-    const dim3 grid(n / 16 + 1, n_chains);
-#define QF_LAUNCH(NW, CPL) hipLaunchKernelGGL((qp_fused_kernel<NW, CPL, 4 * CPL>), grid, dim3(64 * NW), 0, s, A, w, n, epoch)
-    if (n <= 64) QF_LAUNCH(1, 1); else if (n <= 128) QF_LAUNCH(2, 1); else if (n <= 256) QF_LAUNCH(4, 1); else if (n <= 512) QF_LAUNCH(4, 2);
-    else if (n <= 576) QF_LAUNCH(3, 3); else if (n <= 768) QF_LAUNCH(4, 3); else QF_LAUNCH(4, 4);
-#undef QF_LAUNCH
-    DQ_HIP(hipGetLastError());
-    return 0;
-}
-
 int launch_qr_panel(Mat A, QrWork w, int n, int n_chains, hipStream_t s) {
     if (!qr_panel_ok(n, w)) { set_error("panel QR: n must be a multiple of 16 in [16, 1024] and the workspace present"); return -1; }
-    // DQMC_QR_FUSED=0: one launch per panel and per update instead of the single persistent launch (A/B switch for tests and profiling)
-    static const bool use_fused = !(getenv("DQMC_QR_FUSED") && atoi(getenv("DQMC_QR_FUSED")) == 0);
-    if (use_fused && w.fsync && w.fused_epoch != 0) {
-        static const char* absent = getenv("DQMC_DEBUG_QR_ABSENT");          // test hooks of the residency census: see qp_fused_kernel
-        static const char* late = getenv("DQMC_DEBUG_QR_LATE");
-        if (absent) w.debug_absent_blk = atoi(absent);
-        if (late) { w.debug_late_blk = atoi(late); if (const char* c = strchr(late, ':')) w.debug_late_us = atoi(c + 1); }
-        return launch_qr_panel_fused(A, w, n, n_chains, s, w.fused_epoch);
-    }
     const dim3 ugrid(n / 16, n_chains);
     const int tpw = (n / 16 + QP_UW - 1) / QP_UW;
 #define QP_UPD(U, K) do { if (tpw <= 2) hipLaunchKernelGGL((qp_update_kernel<U, 2>), ugrid, dim3(64 * QP_UW), 0, s, A, w, n, K); \
