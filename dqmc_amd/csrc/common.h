@@ -115,6 +115,7 @@ struct QrWork {
 };
 long qr_panel_work_doubles(int n);
 bool qr_panel_ok(int n, const QrWork& w);   // n a multiple of 16 in [16, 1024] and the workspace present
+int launch_qr_panel_formq(QrWork w, Mat L, int n, int n_chains, hipStream_t s);   // explicit Q of that factorisation from its compact-WY factors (left in w.pw)
 int launch_qr_panel(Mat A, QrWork w, int n, int n_chains, hipStream_t s);   // qr_panel.hip: A -> reflectors / R0 in place, tau, jpvt (same format as the QRCP kernels)
 long qrcp_coop_sync_granules(int n);        // granules of cooperative-QRCP workspace per chain
 int qrcp_coop_workgroups(int n, int n_chains);

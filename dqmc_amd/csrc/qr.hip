@@ -362,7 +362,8 @@ static int launch_to_ldr_nr(Mat A, Mat L, Vec d, Mat R, QrWork w, int n, int n_c
         if (NRSEL == -2) DQ_TRY_RC(launch_qr_panel(A, w, n, n_chains, s));
         else if (NRSEL == 0) DQ_TRY_RC(launch_qrcp_colown(A, w, n, n_chains, s));
         else DQ_TRY_RC(launch_qrcp_coop(A, w, n, n_chains, s));
-        if (formq_blocked_ok(n)) launch_formq_blocked(CMat(A), w, L, n, n_chains, s);
+        if (NRSEL == -2) DQ_TRY_RC(launch_qr_panel_formq(w, L, n, n_chains, s));
+        else if (formq_blocked_ok(n)) launch_formq_blocked(CMat(A), w, L, n, n_chains, s);
         else if (n <= 256) hipLaunchKernelGGL((formq_kernel<16>), dim3((n + 15) / 16, n_chains), dim3(256), 0, s, CMat(A), (const double*)w.tau, w.tau_stride,
                                               (const int*)w.jpvt, w.jpvt_stride, L, n);
         else if (n <= 576) hipLaunchKernelGGL((formq_kernel<36>), dim3((n + 15) / 16, n_chains), dim3(256), 0, s, CMat(A), (const double*)w.tau, w.tau_stride,

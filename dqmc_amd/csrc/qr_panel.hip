@@ -271,8 +271,9 @@ __global__ __launch_bounds__(64 * NW) void qp_panel_kernel(Mat Am, QrWork w, int
     double* __restrict__ A = Am.at(chain);
     double* __restrict__ pw = w.pw + (long)chain * w.pw_stride;
     const double* __restrict__ Y = pw;                         // [QP_SR][n]
-    double* __restrict__ Vp = pw + (long)QP_SR * n;           // [n][QP_B] column-major clean copy of the panel's reflectors
-    double* __restrict__ Tm = Vp + (long)QP_B * n;            // [QP_B][QP_B] column-major
+    double* __restrict__ Vp = pw + (long)QP_SR * n + (long)n * k;                 // [n][QP_B] column-major clean copy of THIS panel's reflectors (all panels are kept: qp_formq_kernel)
+    double* __restrict__ Tm = pw + (long)QP_SR * n + (long)n * n + (long)QP_B * k;   // [QP_B][QP_B] column-major, one per panel
+    double* __restrict__ VTp = pw + (long)QP_SR * n + (long)n * n + (long)QP_B * n + (long)n * k;   // the same panel row-major ([n][QP_B]): the operand of V^T A is read along its rows
     int* __restrict__ pivpos = w.pivpos + (long)chain * w.pivpos_stride;
     double* tau = w.tau + (long)chain * w.tau_stride;
     int* jpvt = w.jpvt + (long)chain * w.jpvt_stride;
@@ -281,13 +282,22 @@ __global__ __launch_bounds__(64 * NW) void qp_panel_kernel(Mat Am, QrWork w, int
     // ---- selection ----
     {
         unsigned live = 0u;
-        double y[CPL][QP_SEL];
+        double y[CPL][QP_SEL]; int pp[CPL];
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) {                              // one round of loads: clamped addresses, masked afterwards
+            const int col = t + 64 * NW * q, cc = col < n ? col : n - 1;
+#pragma unroll
+            for (int i = 0; i < QP_SEL; ++i) y[q][i] = Y[(long)i * n + cc];
+            pp[q] = pivpos[cc];
+        }
 #pragma unroll
         for (int q = 0; q < CPL; ++q) {
             const int col = t + 64 * NW * q;
-            if (col < n && pivpos[col] < 0) live |= 1u << q;
+            if (col < n && pp[q] < 0) live |= 1u << q;
+            if (col >= n) {
 #pragma unroll
-            for (int i = 0; i < QP_SEL; ++i) y[q][i] = col < n ? Y[(long)i * n + col] : 0.0;
+                for (int i = 0; i < QP_SEL; ++i) y[q][i] = 0.0;
+            }
         }
 #define QP_SEL_STEP(J) select_step<J, NW, CPL>(y, live, t, lane, wave, sh);
         QP_SEL_STEP(0) QP_SEL_STEP(1) QP_SEL_STEP(2) QP_SEL_STEP(3) QP_SEL_STEP(4) QP_SEL_STEP(5) QP_SEL_STEP(6) QP_SEL_STEP(7)
@@ -330,8 +340,10 @@ __global__ __launch_bounds__(64 * NW) void qp_panel_kernel(Mat Am, QrWork w, int
             for (int i = 0; i < 16; ++i) {
                 const bool below = !isd || i > c;                         // strictly below the column's diagonal: the reflector tail
                 const double v = below ? a[b][i] * myscale : a[b][i];
+                const double vc = below ? v : (i == c ? 1.0 : 0.0);
                 dst[i] = v;
-                vdst[i] = below ? v : (i == c ? 1.0 : 0.0);
+                vdst[i] = vc;
+                VTp[(long)QP_B * (r0 + i) + c] = vc;
             }
         }
     }
@@ -357,8 +369,9 @@ __global__ __launch_bounds__(64 * QP_UW) void qp_update_kernel(Mat Am, QrWork w,
     double* __restrict__ A = Am.at(chain);
     double* __restrict__ pw = w.pw + (long)chain * w.pw_stride;
     double* __restrict__ Y = pw;
-    const double* __restrict__ Vp = pw + (long)QP_SR * n;
-    const double* __restrict__ Tm = Vp + (long)QP_B * n;
+    const double* __restrict__ Vp = pw + (long)QP_SR * n + (long)n * k;
+    const double* __restrict__ Tm = pw + (long)QP_SR * n + (long)n * n + (long)QP_B * k;
+    const double* __restrict__ VTp = pw + (long)QP_SR * n + (long)n * n + (long)QP_B * n + (long)n * k;
     int* __restrict__ pivpos = w.pivpos + (long)chain * w.pivpos_stride;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int r16 = lane & 15, kk = lane >> 4;
@@ -382,7 +395,7 @@ __global__ __launch_bounds__(64 * QP_UW) void qp_update_kernel(Mat Am, QrWork w,
             for (int r = 0; r < 4; ++r) At[ti][r] = Ac[r0 + kk + 4 * r];
             if (UPDATE) {
 #pragma unroll
-                for (int s = 0; s < 4; ++s) { v1[ti][s] = Vp[(long)n * r16 + (r0 + kk + 4 * s)]; v2[ti][s] = -Vp[(long)n * (kk + 4 * s) + (r0 + r16)]; }
+                for (int s = 0; s < 4; ++s) { v1[ti][s] = VTp[(long)QP_B * (r0 + kk + 4 * s) + r16]; v2[ti][s] = Vp[(long)n * (kk + 4 * s) + (r0 + r16)]; }   // both along the lanes' fast index
             }
         }
     }
@@ -415,6 +428,7 @@ __global__ __launch_bounds__(64 * QP_UW) void qp_update_kernel(Mat Am, QrWork w,
         // W' = T^T W: a = T[i = kk + 4 s][i' = r16], b = W[kk + 4 s][c] (the accumulator registers as they are)
 #pragma unroll
         for (int s = 0; s < 4; ++s) wp = __builtin_amdgcn_mfma_f64_16x16x4f64(tv[s], W[s], wp, 0, 0, 0);
+        wp = -wp;                                                 // A - V W'
         __syncthreads();
     }
     d4 ya[YT];
@@ -457,8 +471,107 @@ __global__ __launch_bounds__(64 * QP_UW) void qp_update_kernel(Mat Am, QrWork w,
     }
 }
 
+// Q = H_0 H_1 ... H_{n/16 - 1} applied to I, every factor in its compact-WY form I - V_k T_k V_k^T (the clean reflector panels and the
+// T factors the panel kernel left behind): grid.x = n / 16 column blocks of Q, each kept in registers as accumulator tiles (tile rt =
+// wave + QP_UW ti) through all the factors that touch it -- columns 16 cb .. 16 cb + 15 of the identity are unchanged by the panels
+// k > cb (their reflectors start below row 16 k), so block cb applies panels k = cb .. 0 -- two MFMA products and one LDS reduction
+// per factor, the next factor's operands requested while the current one is multiplied.  77 us (formq_blocked_kernel: one column per
+// 16-lane row, reflector by reflector) -> the figure in DESIGN at n = 256.
+template <int TPW>
+__global__ __launch_bounds__(64 * QP_UW) void qp_formq_kernel(QrWork w, Mat Lm, int n) {
+    __shared__ double red[QP_UW][4][64];
+    const int chain = blockIdx.y;
+    const double* __restrict__ pw = w.pw + (long)chain * w.pw_stride;
+    const double* __restrict__ Vall = pw + (long)QP_SR * n;
+    const double* __restrict__ Tall = Vall + (long)n * n;
+    const double* __restrict__ VTall = Tall + (long)QP_B * n;
+    double* __restrict__ L = Lm.at(chain);
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int r16 = lane & 15, kk = lane >> 4;
+    const int cb = blockIdx.x, col = 16 * cb + r16;
+    const int n_tiles = n / 16;
+    d4 Qt[TPW];
+#pragma unroll
+    for (int ti = 0; ti < TPW; ++ti) {
+        const int rt = wave + QP_UW * ti;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Qt[ti][r] = (16 * rt + kk + 4 * r == col) ? 1.0 : 0.0;
+    }
+    double v1[TPW][4], v2[TPW][4], tv[4], n1[TPW][4], n2[TPW][4], nt_[4];
+    auto load = [&](int k, double (&a1)[TPW][4], double (&a2)[TPW][4], double (&at)[4]) {
+        const double* Vp = Vall + (long)n * 16 * k;
+        const double* Tm = Tall + (long)QP_B * 16 * k;
+        const double* VTp = VTall + (long)n * 16 * k;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) at[s] = Tm[r16 + QP_B * (kk + 4 * s)];          // W' = T W: a = T[i' = r16][i = kk + 4 s]
+#pragma unroll
+        for (int ti = 0; ti < TPW; ++ti) {
+            const int rt = wave + QP_UW * ti;
+            const bool in = rt < n_tiles && rt >= k;                                // rows of the factor: 16 k .. n - 1
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                a1[ti][s] = in ? VTp[(long)QP_B * (16 * rt + kk + 4 * s) + r16] : 0.0;
+                a2[ti][s] = in ? Vp[(long)n * (kk + 4 * s) + (16 * rt + r16)] : 0.0;
+            }
+        }
+    };
+    load(cb, v1, v2, tv);
+    for (int k = cb; k >= 0; --k) {
+        if (k > 0) load(k - 1, n1, n2, nt_);
+        d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ti = 0; ti < TPW; ++ti)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v1[ti][s], Qt[ti][s], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave][r][lane] = acc[r];
+        __syncthreads();
+        d4 W;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            double v = red[0][r][lane];
+#pragma unroll
+            for (int q = 1; q < QP_UW; ++q) v += red[q][r][lane];
+            W[r] = v;
+        }
+        d4 wp = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) wp = __builtin_amdgcn_mfma_f64_16x16x4f64(tv[s], W[s], wp, 0, 0, 0);
+        wp = -wp;
+#pragma unroll
+        for (int ti = 0; ti < TPW; ++ti)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) Qt[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(v2[ti][s], wp[s], Qt[ti], 0, 0, 0);   // v2 = 0 above the factor's rows
+        __syncthreads();
+#pragma unroll
+        for (int ti = 0; ti < TPW; ++ti)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) { v1[ti][s] = n1[ti][s]; v2[ti][s] = n2[ti][s]; }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) tv[s] = nt_[s];
+    }
+#pragma unroll
+    for (int ti = 0; ti < TPW; ++ti) {
+        const int rt = wave + QP_UW * ti;
+        if (rt < n_tiles) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) L[(long)n * col + 16 * rt + kk + 4 * r] = Qt[ti][r];
+        }
+    }
+}
+
+int launch_qr_panel_formq(QrWork w, Mat L, int n, int n_chains, hipStream_t s) {
+    const dim3 grid(n / 16, n_chains);
+    const int tpw = (n / 16 + QP_UW - 1) / QP_UW;
+    if (tpw <= 2) hipLaunchKernelGGL((qp_formq_kernel<2>), grid, dim3(64 * QP_UW), 0, s, w, L, n);
+    else if (tpw <= 5) hipLaunchKernelGGL((qp_formq_kernel<5>), grid, dim3(64 * QP_UW), 0, s, w, L, n);
+    else hipLaunchKernelGGL((qp_formq_kernel<8>), grid, dim3(64 * QP_UW), 0, s, w, L, n);
+    DQ_HIP(hipGetLastError());
+    return 0;
+}
+
 bool qr_panel_ok(int n, const QrWork& w) { return n >= 16 && n <= 1024 && n % 16 == 0 && w.pw != nullptr && w.pivpos != nullptr && w.pw_stride >= qr_panel_work_doubles(n); }
-long qr_panel_work_doubles(int n) { return (long)(QP_SR + QP_B) * n + QP_B * QP_B; }
+long qr_panel_work_doubles(int n) { return (long)(QP_SR + 2 * n) * n + (long)QP_B * n; }   // Y | V panels | T factors | V panels row-major
 
 int launch_qr_panel(Mat A, QrWork w, int n, int n_chains, hipStream_t s) {
     if (!qr_panel_ok(n, w)) { set_error("panel QR: n must be a multiple of 16 in [16, 1024] and the workspace present"); return -1; }
