@@ -84,10 +84,8 @@ int launch_cb_apply(const CbDesc& d, int n_chains, hipStream_t s) {
     if (d.n <= 0 || d.n > 4096 || d.n_groups <= 0 || !d.partner || !d.par || !d.in.p || (!d.out.p && !d.outT.p)) { set_error("launch_cb_apply: bad argument"); return -1; }
     if (d.outT.p && d.outT.p == d.in.p) { set_error("launch_cb_apply: the transposed output may not alias the input"); return -1; }
     const int n = d.n;
-    static const int forced = getenv("DQMC_CB_COLS") ? atoi(getenv("DQMC_CB_COLS")) : 0;       // A/B switch: columns per workgroup
     // columns per workgroup: 64 KiB of LDS hold the two strips and (when they fit beside them) the pair tables
     int cb = n <= 320 ? 2 : n <= 1024 ? 4 : n <= 2048 ? 2 : 1;     // measured (scripts/cb_time.py): 4.6 us at N = 256 with 2, 7.7 us at N = 576 with 2 or 4
-    if (forced == 8 || forced == 4 || forced == 2 || forced == 1) cb = forced;
     while (cb > 1 && (size_t)2 * cb * n * sizeof(double) > 65536) cb >>= 1;
     size_t lds = (size_t)2 * cb * n * sizeof(double);
     const size_t tables = (size_t)d.n_groups * n * sizeof(int);

@@ -186,7 +186,7 @@ constexpr int UPDATE_KD = 32;    // delayed-update window (accepted flips per fl
 //   tag = (epoch << 8) | window,   epoch = 1, 2, ... per launch on the engine (UpdateDesc::slice_epoch), window = 0 .. 255
 // so a word left behind by an earlier launch can never match and nothing has to be re-armed when a launch ends (the round-2
 // kernels zeroed the words through an exit ticket: 66 stores and one atomic per workgroup on the tail of every launch).  The host
-// zeroes the block and restarts the epoch before it reaches 2^24 (Engine::next_slice_epoch).
+// zeroes the block and restarts the epoch before it reaches 2^24 (Engine::local_update, engine.hip).
 //   seq       walk -> flush: high word = tag of the window just closed, low word = k | solo << 30 | final << 31
 //   arrive[f] flush -> walk: tag of the last window flush workgroup f has absorbed; window 0 = "resident" (the census)
 struct SliceSync {

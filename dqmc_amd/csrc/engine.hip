@@ -262,7 +262,7 @@ struct Engine {
     bool utTri[2] = {false, false}; bool ut_valid = false;
     double* utMeasNow = nullptr; double* utMeasSum = nullptr; long long ut_meas_count = 0;     // [C][3][nt + 1][n] dynamical observables: last / bin sums
     long long meas_count = 0;                                    // measurements accumulated in meas_sum
-    char* slice_sync = nullptr;                                  // [C][1 KiB] hand-off words of the persistent slice kernels
+    char* slice_sync = nullptr;                                  // [C][SLICE_SYNC_BYTES = 2 KiB] hand-off words of the persistent slice kernels (SliceSync, common.h)
     bool persistent = false;                                     // holds a CU reservation for the single-launch slice kernel (slice_reserve)
     bool handoff_failed = false;                                 // a hand-off of a persistent kernel timed out once: this engine stays on the kernel pairs from then on
     unsigned slice_epoch = 0;                                    // launches of the persistent slice kernel so far: the tag of its hand-off words (SliceSync, common.h)
@@ -424,8 +424,7 @@ struct Engine {
         // kernels' chain dimension -- n_stab - 1 launches of the 64x64-tile GEMM for all blocks, one QRCP launch with a workgroup
         // per block on its own CU (20 x 0.84 ms side by side instead of in a row) -- and only the n_stack - 1 ldr_mul_ldr products,
         // which are a chain, stay sequential.  Halves the cost of an initialisation, i.e. of a replica-exchange round.
-        static const bool no_batch = getenv("DQMC_INIT_SEQUENTIAL") != nullptr;      // A/B switch
-        if (C == 1 && n <= 256 && nt % n_stab == 0 && n_stack >= 2 && !no_batch) return init_batched();
+        if (C == 1 && n <= 256 && nt % n_stab == 0 && n_stack >= 2) return init_batched();
         LdrRef tmp{Mat{tmpL, nn}, Vec{tmpD, (long)n}, Mat{tmpR, nn}};
         for (int i = n_stack - 1; i >= 0; --i) {
             Mat bb; DQ_TRY(Bbar(i, &bb));

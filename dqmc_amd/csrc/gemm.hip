@@ -415,8 +415,7 @@ int launch_gemm(const GemmDesc& g, int n_chains, hipStream_t s) {
 
 static int launch_gemm_main(const GemmDesc& g, int n_chains, hipStream_t s, bool* ct_done) {
     const int n = g.n;
-    static const bool no_tile64 = getenv("DQMC_GEMM_NO_TILE64") != nullptr;
-    if (!no_tile64 && n % 64 == 0 && (long)n_chains * (n / 64) * (n / 64) >= 256) {     // enough 64x64 tiles to fill 256 CUs
+    if (n % 64 == 0 && (long)n_chains * (n / 64) * (n / 64) >= 256) {     // enough 64x64 tiles to fill 256 CUs
         const int tiles = n / 64;
         dim3 grid(tiles * tiles, n_chains), block(256);
         if (g.transA) hipLaunchKernelGGL((gemm_tile64_kernel<true>), grid, block, 0, s, g, tiles);
@@ -424,8 +423,7 @@ static int launch_gemm_main(const GemmDesc& g, int n_chains, hipStream_t s, bool
         DQ_HIP(hipGetLastError());
         return 0;
     }
-    static const bool no_stage32 = getenv("DQMC_GEMM_NO_STAGE32") != nullptr;      // A/B switch
-    if (n >= 384 && !no_stage32) {                                                 // measured: 13.7 vs 10.9 us at n = 324, 15 vs 22 at 400, 31 vs 45 at 576
+    if (n >= 384) {                                                 // measured: 13.7 vs 10.9 us at n = 324, 15 vs 22 at 400, 31 vs 45 at 576
         const int T = (n + 31) / 32, chunk = (T * T + 7) / 8;
         dim3 grid(8 * chunk, n_chains), block(256);
         // (64-deep stages measured no faster: 24.9 against 23.0 us at n = 576, with 250 VGPRs)

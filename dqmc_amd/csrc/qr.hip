@@ -396,10 +396,9 @@ int launch_to_ldr(Mat A, Mat L, Vec d, Mat R, QrWork w, int n, int n_chains, hip
     if (n > 1024) { set_error("to_LDR kernel supports n <= 1024"); return -1; }
     static const bool force_stream = getenv("DQMC_QR_STREAMING") != nullptr;    // A/B switch for tests and profiling
     // panel-pivoted blocked QR (qr_panel.hip): one global pivot decision per 16 columns instead of one per column.  DQMC_QR_PANEL=0 keeps the
-    // column-pivoted kernels (A/B switch for tests and profiling), DQMC_QR_PANEL_MIN_N moves the size from which the panel path is taken
+    // column-pivoted kernels at every size (test switch: the only way to reach qr_colown / qr_coop at n = 64 .. 1024 with few chains)
     static const bool use_panel = !(getenv("DQMC_QR_PANEL") && atoi(getenv("DQMC_QR_PANEL")) == 0);
-    static const int panel_min_n = getenv("DQMC_QR_PANEL_MIN_N") ? atoi(getenv("DQMC_QR_PANEL_MIN_N")) : 64;
-    if (use_panel && !force_stream && n >= panel_min_n && n_chains <= 8 && qr_panel_ok(n, w)) return launch_to_ldr_nr<-2>(A, L, d, R, w, n, n_chains, s);
+    if (use_panel && !force_stream && n >= 64 && n_chains <= 8 && qr_panel_ok(n, w)) return launch_to_ldr_nr<-2>(A, L, d, R, w, n, n_chains, s);
     if (n <= 256 && !force_stream) return launch_to_ldr_nr<0>(A, L, d, R, w, n, n_chains, s);
     // n > 256: the matrix does not fit one CU; ceil(n/32) cooperating workgroups while they fit the CU budget (co-residency), the
     // single-workgroup streaming kernel otherwise (many chains per launch: every CU is busy with its own chain anyway)

@@ -50,6 +50,7 @@ static int have_device() {
 
 // pairwise exchange of device buffers on `s`
 static int p2p(dqmc_comm* c, const void* send, void* recv, size_t bytes, int partner, int tag, hipStream_t s) {
+    if (c->rccl && !c->nc) { set_error("communicator aborted after an earlier wire error: destroy it and create a new one"); return DQMC_EINVAL; }
     if (c->rccl) {
         DQ_NCCL(ncclGroupStart());
         DQ_NCCL(ncclSend(send, bytes, ncclInt8, partner, c->nc, s));
@@ -139,6 +140,7 @@ const char* dqmc_comm_transport(dqmc_comm* c) { return !c ? "" : c->rccl ? "rccl
 int dqmc_comm_allreduce_sum(dqmc_comm* c, double* x, int count) {
     if (!c || !x || count < 1 || count > 4) { set_error("allreduce_sum: 1..4 doubles"); return DQMC_EINVAL; }
     if (c->world == 1) return 0;
+    if (c->rccl && !c->nc) { set_error("communicator aborted after an earlier wire error: destroy it and create a new one"); return DQMC_EINVAL; }
     if (c->rccl) {
         DQ_HIP(hipSetDevice(c->device));
         DQ_HIP(hipMemcpyAsync(c->dbuf, x, sizeof(double) * count, hipMemcpyHostToDevice, c->stream));
@@ -171,6 +173,7 @@ int dqmc_comm_allreduce_sum(dqmc_comm* c, double* x, int count) {
 int dqmc_comm_selftest(dqmc_comm* c) {
     if (!c) { set_error("comm_selftest: null communicator"); return DQMC_EINVAL; }
     if (!c->rccl) { set_error("comm_selftest: RCCL transport only (a callback transport is checked by calling the callback)"); return DQMC_EINVAL; }
+    if (!c->nc) { set_error("communicator aborted after an earlier wire error: destroy it and create a new one"); return DQMC_EINVAL; }
     DQ_HIP(hipSetDevice(c->device));
     const size_t bytes = 4096;
     int8_t* a = nullptr; int8_t* b = nullptr;

@@ -1005,11 +1005,9 @@ int launch_update_slice(const UpdateDesc& d, int l, int acc_slot, int n_chains, 
         DQ_HIP(hipGetLastError());
         return 0;
     }
-    static const bool pairs = getenv("DQMC_SLICE_PAIRS") != nullptr;                   // A/B switch: scan / flush kernel pairs
     // measured (cfg 3, sweeps/s, solo vs pairs): 64 chains 166 / 214, 128 chains 251 / 275, 256 chains 324 / 307 -- a chain's own CU
     // flushes slower than the whole chip does, so the solo kernel pays once there are enough chains to occupy every CU
-    static const bool solo_forced = getenv("DQMC_SLICE_SOLO") != nullptr;
-    if (regs && !pairs && !multi_kernel && (n_chains >= 224 || solo_forced)) {
+    if (regs && !multi_kernel && n_chains >= 224) {
         hipLaunchKernelGGL(slice_solo_kernel, dim3(1, n_chains), dim3(256), lds, s, d, l, acc_slot, kd, 0);
         DQ_HIP(hipGetLastError());
         return 0;

@@ -51,7 +51,15 @@ World world_from_env() {
 dqmc_comm* rccl_world(const World& w, int device) {
     std::string path;
     if (const char* p = std::getenv("DQMC_RENDEZVOUS_FILE")) path = p;
-    else { mkdir("results", 0755); path = "results/.dqmc_rccl_id." + std::to_string((long)getppid()); }
+    else {
+        // one file per RUN: the launcher's pid plus, when the launcher exports one, its per-run nonce (torchrun: TORCHELASTIC_RUN_ID; mpirun:
+        // OMPI_MCA_ess_base_jobid / PMI_JOBID; or DQMC_RUN_ID set by hand), so that a file a crashed earlier run of a recycled pid left
+        // behind is never this run's
+        std::string nonce;
+        for (const char* k : {"DQMC_RUN_ID", "TORCHELASTIC_RUN_ID", "OMPI_MCA_ess_base_jobid", "PMI_JOBID", "SLURM_JOB_ID"})
+            if (const char* v = std::getenv(k)) { nonce = std::string(".") + v; break; }
+        mkdir("results", 0755); path = "results/.dqmc_rccl_id." + std::to_string((long)getppid()) + nonce;
+    }
     char id[DQMC_UNIQUE_ID_BYTES];
     if (w.rank == 0) {
         dqmc_detail::check(dqmc_comm_unique_id(id));

@@ -19,5 +19,5 @@ for cfg in (sys.argv[1:] or ["cfg3", "cfg5"]):
         for _ in range(200):
             e.wrap_forward(0); e.wrap_backward(0)
         e.sync(); dt = time.perf_counter() - t0
-        print(f"{cfg} n={m.n} {'checkerboard' if cb else 'dense GEMM  '} {1e6 * dt / 800:.2f} us per launch  cols={os.environ.get('DQMC_CB_COLS', 'default')}", flush=True)
+        print(f"{cfg} n={m.n} {'checkerboard' if cb else 'dense GEMM  '} {1e6 * dt / 800:.2f} us per launch", flush=True)
         e.close()

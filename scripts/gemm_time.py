@@ -22,5 +22,5 @@ for spec in (sys.argv[1:] or ["16", "18", "20", "24", "32"]):
     for _ in range(100):
         e.wrap_forward(0); e.wrap_backward(0)
     e.sync(); dt = time.perf_counter() - t0
-    print(f"n={n}: {1e6 * dt / 400:.2f} us per GEMM launch ({2.0 * n ** 3 / (dt / 400) / 1e12:.1f} TFLOP/s)  NO_STAGE32={os.environ.get('DQMC_GEMM_NO_STAGE32', '')}", flush=True)
+    print(f"n={n}: {1e6 * dt / 400:.2f} us per GEMM launch ({2.0 * n ** 3 / (dt / 400) / 1e12:.1f} TFLOP/s)", flush=True)
     e.close()

@@ -487,7 +487,7 @@ def test_set_G_and_reinit_are_consistent(hip, orc):
 
 def test_alternative_kernel_paths_in_subprocess(hip):
     """Every env-switch kernel variant that is still shipped (the sub-matrix walk, the scan / flush kernel pairs, the solo slice
-    kernel, dgetrf + dgetrs instead of Gauss-Jordan, the streaming QRCP, the block-by-block initialisation)
+    kernel, dgetrf + dgetrs instead of Gauss-Jordan, the streaming and the column-pivoted QRCP instead of the panel-pivoted one)
     runs the golden fixtures in a fresh process (the switches are read once per process) and is compared ELEMENT-WISE with the
     independent numpy evaluation stored there: G(0,0), log det, G and the HS fields after a full sweep at cfg 2 and cfg 3, and the
     same for every chain of a 4-chain batched engine at cfg 2."""
@@ -513,8 +513,8 @@ def test_alternative_kernel_paths_in_subprocess(hip):
         out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
         assert out.returncode == 0, (env_extra, out.stderr[-2000:])
         return json.loads(out.stdout.strip().splitlines()[-1])
-    for env in ({}, {"DQMC_WALK_SUBMATRIX": "1"}, {"DQMC_SLICE_MULTIKERNEL": "1"}, {"DQMC_SLICE_PAIRS": "1"}, {"DQMC_SLICE_SOLO": "1"}, {"DQMC_LU_CLASSIC": "1"},
-                {"DQMC_QR_STREAMING": "1"}, {"DQMC_QR_PANEL": "0"}, {"DQMC_INIT_SEQUENTIAL": "1"}):
+    for env in ({}, {"DQMC_WALK_SUBMATRIX": "1"}, {"DQMC_SLICE_MULTIKERNEL": "1"}, {"DQMC_LU_CLASSIC": "1"},
+                {"DQMC_QR_STREAMING": "1"}, {"DQMC_QR_PANEL": "0"}):
         got = run(env)
         print(env, {k: (v["d0"], v["dA"]) if "d0" in v else v["dA"] for k, v in got.items()})
         for name in ("cfg2_therm", "cfg3_therm"):
@@ -541,7 +541,7 @@ def test_alternative_kernel_paths_above_256_in_subprocess(hip):
             "    e = m.engine(dqmc_amd.lib()); e.set_fields(f); e.init(); G0 = e.get_G(); e.sweep_0_to_beta(*st)\n"
             "    np.savez(sys.argv[1] + str(L) + '.npz', G0=G0, G1=e.get_G(), f=e.get_fields(), acc=e.stats().n_accepted)\n") % root
     ref = {L: body(L) for L in (24, 20)}
-    for env in ({"DQMC_GEMM_NO_STAGE32": "1"}, {"DQMC_GJ_MAX_N": "256"}, {"DQMC_QR_STREAMING": "1"}, {"DQMC_QR_PANEL": "0"}, {"DQMC_SLICE_MULTIKERNEL": "1"}):
+    for env in ({"DQMC_GJ_MAX_N": "256"}, {"DQMC_QR_STREAMING": "1"}, {"DQMC_QR_PANEL": "0"}, {"DQMC_SLICE_MULTIKERNEL": "1"}):
         with tempfile.TemporaryDirectory() as td:
             e2 = dict(os.environ); e2.update(env)
             out = subprocess.run([sys.executable, "-c", code, os.path.join(td, "r")], env=e2, capture_output=True, text=True, timeout=600)
@@ -726,8 +726,8 @@ def test_dynamical_observables_parity(hip, orc, shape):
 
 
 def test_batched_engine_matches_single_chain_engines(hip):
-    """Four cfg-3 chains in one engine (scan / flush kernel pairs; the solo kernel when DQMC_SLICE_SOLO is set or there are >= 224
-    chains -- exercised in the subprocess test below) against four single-chain engines (single-launch slice kernel): same accepted
+    """Four cfg-3 chains in one engine (scan / flush kernel pairs; the solo kernel takes over from 224 chains on:
+    test_solo_slice_kernel_from_224_chains_on) against four single-chain engines (single-launch slice kernel): same accepted
     flips and fields, G to 1e-9 of its largest entry (the flushes sum in a different order)."""
     m = HubbardModel(**CONFIGS["cfg3"]); rng = np.random.default_rng(77)
     C = 4
@@ -743,6 +743,27 @@ def test_batched_engine_matches_single_chain_engines(hip):
         G1 = e1.get_G()
         assert np.array_equal(fb[c], e1.get_fields()) and stb[c].n_accepted == e1.stats().n_accepted
         assert np.abs(Gb[c] - G1).max() < 1e-9 * max(1.0, np.abs(G1).max())
+
+
+def test_solo_slice_kernel_from_224_chains_on(hip, orc):
+    """From 224 chains per engine every chain walks AND flushes on its own CU (slice_solo_kernel: launch_update_slice, update.hip) --
+    the deployment shape that fills the chip.  240 chains of the 4x4 lattice, each with its own fields and random stream, against 240
+    oracle runs: fields and accepted counts exact, G to 1e-10 of its largest entry."""
+    m = HubbardModel(**CONFIGS["cfg1"]); rng = np.random.default_rng(88)
+    C = 240
+    fs = np.stack([m.random_fields(500 + c) for c in range(C)])
+    per_f = [m.random_stream(rng) for _ in range(C)]; per_b = [m.random_stream(rng) for _ in range(C)]
+    sf = tuple(np.stack([x[q] for x in per_f]) for q in range(3)); sb = tuple(np.stack([x[q] for x in per_b]) for q in range(3))
+    eb = m.engine(hip, n_chains=C); eb.set_fields(fs); eb.init()
+    eb.sweep_0_to_beta(*sf); eb.sweep_beta_to_0(*sb)
+    Gb, fb, stb = eb.get_G(), eb.get_fields(), eb.stats()
+    o = m.engine(orc)
+    for c in range(C):
+        o.set_fields(fs[c]); o.init(); n0 = o.stats().n_accepted
+        o.sweep_0_to_beta(*per_f[c]); o.sweep_beta_to_0(*per_b[c])
+        assert np.array_equal(fb[c], o.get_fields()) and stb[c].n_accepted == o.stats().n_accepted - n0, c
+        assert close(Gb[c], o.get_G()), c
+    eb.close()
 
 
 def test_bitwise_reproducible_at_full_size(hip):
