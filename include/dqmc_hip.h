@@ -76,8 +76,16 @@ int dqmc_device_count(void);
  * stablelinalg:: directly.
  * ------------------------------------------------------------------------ */
 
-/* stablelinalg::to_LDR (source/stablelinalg.cpp:35-55): column-pivoted
- * Householder QR, M P = Q R0; d = |diag R0|; R = diag(1/d) R0 P^T; L = Q.    */
+/* stablelinalg::to_LDR (source/stablelinalg.cpp:35-55): pivoted Householder
+ * QR, M P = Q R0; d = |diag R0|; R = diag(1/d) R0 P^T; L = Q.  For n a
+ * multiple of 16 in [64, 1024] P is chosen one 16-column PANEL at a time
+ * (randomised panel pivoting, qr_panel.hip) instead of one column at a time
+ * (dgeqp3): L is orthogonal and L diag(d) R = M to rounding as before, every
+ * row of R still has its unit entry in the pivot's column, but |R_ij| <= ~1.1
+ * and d is graded to a factor ~2 instead of exactly -- what the reference's
+ * consumers (inv_I_plus_ldr*, the stack) rely on is the product and the
+ * grading.  Other sizes, and every size when DQMC_QR_PANEL=0 is set, return
+ * dgeqp3's own pivot order.                                                   */
 int dqmc_to_ldr(int n, const double* M, double* L, double* d, double* R);
 
 /* stablelinalg::ldr_mul_mat (source/stablelinalg.cpp:57-67): F' = F * M.     */
