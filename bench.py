@@ -142,7 +142,7 @@ def cpu_baseline(model, seed, budget_s=20.0, lib=None, device=0, config="cfg3"):
 
 def pmc_traffic(config, chains):
     """Measured HBM bytes per launch of the dominant kernel (counter passes committed under profiles/), or None."""
-    path = os.path.join(ROOT, "profiles", "r03_pmc_slice_kernel.json")
+    path = os.path.join(ROOT, "profiles", "r04_pmc_slice_kernel.json")
     if config != "cfg3" or chains != 1 or not os.path.exists(path):
         return None
     return float(json.load(open(path))["traffic_bytes_per_launch"])
@@ -374,7 +374,7 @@ def main():
                                                                          "slice_sm_kernel: sub-matrix walk + flush roles") + ")", "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          # HBM-side bytes per launch from rocprofv3 PMC passes of this round's binary on the same start state (FETCH_SIZE x2
-                         # gfx950 correction + WRITE_SIZE, separate passes; profiles/r03_pmc_slice_kernel.json names the CSVs and the command);
+                         # gfx950 correction + WRITE_SIZE, separate passes; profiles/r04_pmc_slice_kernel.json names the CSVs and the command);
                          # cfg3, single chain, single-launch path only
                          "traffic": pmc_traffic(args.config, C),
                          "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_launch_s * 1e3,

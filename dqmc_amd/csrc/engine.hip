@@ -241,6 +241,7 @@ struct Engine {
     UpdateTables* tabs = nullptr; double* tab8 = nullptr;        // [C], [C][8]
     bool gt_valid = false;                                       // GT == G^T right now (set by the wraps, cleared by everything else that writes G)
     double* G = nullptr; double* Gtmp = nullptr; double* GT = nullptr;   // [C][nn]; GT: transposed copy for the local-update walk
+    double* pg_eye = nullptr; double* pg_ones = nullptr;         // identity [nn] and ones [n]: operands of the first piggybacked B-bar factor of a block (single chain)
     double* bb0 = nullptr; double* bb1 = nullptr;                // Bbar ping-pong
     double* stackL = nullptr; double* stackD = nullptr; double* stackR = nullptr;
     double* tmpL = nullptr; double* tmpD = nullptr; double* tmpR = nullptr;   // one spare LDR (init_stacks)
@@ -295,7 +296,7 @@ struct Engine {
         if (persistent) slice_release(device, n, C);
         for (auto& p : ev_pairs) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
         if (stage_free) (void)hipEventDestroy(stage_free);
-        void* ptrs[] = {expKh, invexpKh, hwOut, utMeasNow, utMeasSum, utG[0], utG[1], utG[2], utTmp, utErr, utL[0], utL[1], utD[0], utD[1], utR[0], utR[1], utP[0], utP[1], meas_now, meas_sum, GT, slice_sync, prep, stackP, expK, invexpK, cb_partner, cb_par, fields, expv, invexpv, tabs, tab8, G, Gtmp, bb0, bb1, stackL, stackD, stackR, tmpL, tmpD, tmpR,
+        void* ptrs[] = {expKh, invexpKh, hwOut, utMeasNow, utMeasSum, utG[0], utG[1], utG[2], utTmp, utErr, utL[0], utL[1], utD[0], utD[1], utR[0], utR[1], utP[0], utP[1], meas_now, meas_sum, GT, slice_sync, prep, stackP, expK, invexpK, cb_partner, cb_par, fields, expv, invexpv, tabs, tab8, G, pg_eye, pg_ones, Gtmp, bb0, bb1, stackL, stackD, stackR, tmpL, tmpD, tmpR,
                         logdet, rs_perm, rs_k, rs_u, Upanel, Wpanel, Cpanel, ibuf, ijp, state, acc, err, dstats, r1scratch};
         for (void* p : ptrs) if (p) (void)hipFree(p);
         if (h_stage) (void)hipHostFree(h_stage);
@@ -317,6 +318,7 @@ struct Engine {
         DQ_TRY(dalloc(&expK, C * nn)); DQ_TRY(dalloc(&invexpK, C * nn));
         DQ_TRY(dalloc(&fields, (size_t)C * nt * n)); DQ_TRY(dalloc(&expv, (size_t)C * nt * n)); DQ_TRY(dalloc(&invexpv, (size_t)C * nt * n));
         DQ_TRY(dalloc(&tabs, C)); DQ_TRY(dalloc(&tab8, (size_t)C * 8));
+        if (C == 1) { DQ_TRY(dalloc(&pg_eye, nn)); DQ_TRY(dalloc(&pg_ones, (size_t)n)); DQ_TRY(launch_set_identity(Mat{pg_eye, nn}, n, 1, s)); const std::vector<double> one_h((size_t)n, 1.0); DQ_HIP(hipMemcpy(pg_ones, one_h.data(), sizeof(double) * n, hipMemcpyHostToDevice)); }
         DQ_TRY(dalloc(&G, C * nn)); DQ_TRY(dalloc(&Gtmp, C * nn)); DQ_TRY(dalloc(&GT, C * nn)); DQ_TRY(dalloc(&bb0, C * nn)); DQ_TRY(dalloc(&bb1, C * nn));
         DQ_TRY(dalloc(&stackL, (size_t)n_stack * C * nn)); DQ_TRY(dalloc(&stackD, (size_t)n_stack * C * n)); DQ_TRY(dalloc(&stackR, (size_t)n_stack * C * nn));
         DQ_TRY(dalloc(&stackP, (size_t)n_stack * C * n)); stack_tri.reset(new bool[n_stack]());
@@ -484,6 +486,31 @@ struct Engine {
         gt_valid = use_gt();                                          // the GEMM that writes G writes GT as well
         return ctx.gemm(ctx.T(0), CMat(invexpK, nn), mG(), ev(l), CVec(), iev(l), 0, 0, use_gt() ? Mat{GT, nn} : Mat{nullptr, 0});
     }
+    // The B-bar chain rides on the wraps (single chain, dense kinetic factor, N <= 256: the regime where a 256^3 product IS its launch).
+    // calculate_Bbar (source/dqmc.cpp:88-105) is n_stab - 1 dependent products per stabilisation, 5.6 us each of which ~4.5 us are the launch:
+    // each of them has an operand in common with a wrap product of the same sweep, so it is computed as a SECOND "chain" of that launch
+    // (the GEMM kernels take the chain index in blockIdx.y and per-operand chain strides: chain 1's operands are simply other buffers).
+    //   forward  (wrap BEFORE the update of its slice): the wrap of slice l starts with expK * G; beside it P <- diag(e^{V_{l-1}}) expK P
+    //            with the fields slice l - 1 has just been given -- the factor of the block's last slice is one explicit product;
+    //   backward (wrap AFTER the update): the wrap of slice l ends with T diag(e^{V_l}) expK; beside it P <- P diag(e^{V_l}) expK = P B_l.
+    // The first factor of a block multiplies the identity.  Same products, same kernel, same association in the forward sweep as Bbar();
+    // in the backward sweep the chain is associated from the other end.
+    bool piggyback() const { return C == 1 && !cb && n <= 256 && pg_eye != nullptr; }
+    int wrap_forward_piggy(int l, const double* Pprev, double* Pnext) {
+        GemmDesc g; g.A = CMat(expK, 0); g.B = CMat(G, (long)(Pprev - G)); g.C = Mat{ctx.T(0).p, (long)(Pnext - ctx.T(0).p)};
+        g.rs = CVec(pg_ones, (long)((expv + (long)(l - 1) * n) - pg_ones)); g.n = n;
+        DQ_TRY(launch_gemm(g, 2, s));
+        gt_valid = use_gt();
+        return ctx.gemm(ctx.T(0), CMat(invexpK, nn), mG(), ev(l), CVec(), iev(l), 0, 0, use_gt() ? Mat{GT, nn} : Mat{nullptr, 0});
+    }
+    int wrap_backward_piggy(int l, const double* Pprev, double* Pnext) {
+        DQ_TRY(ctx.gemm(CMat(invexpK, nn), mG(), ctx.T(0), CVec(), iev(l)));
+        gt_valid = use_gt();
+        GemmDesc g; g.A = CMat(ctx.T(0).p, (long)(Pprev - ctx.T(0).p)); g.B = CMat(expK, 0); g.C = Mat{G, (long)(Pnext - G)};
+        g.ks = CVec(expv + (long)l * n, 0); g.n = n;
+        if (use_gt()) g.CT = Mat{GT, (long)(ctx.T(1).p - GT)};          // chain 1's transposed copy goes to scratch
+        return launch_gemm(g, 2, s);
+    }
     // DQMC::propagate_GF_backward (source/dqmc.cpp:169-187): G = B_l^-1 G B_l
     int wrap_backward(int l) {
         if (cb) {
@@ -552,13 +579,21 @@ struct Engine {
     int sweep_fwd() {
         int n_err = 0;
         DQ_HIP(hipMemsetAsync(err, 0, sizeof(double) * C * n_stack, s));             // max_abs_diff folds into zeroed slots
+        const bool pg = piggyback();
+        double* Pcur = bb0; double* Pnxt = bb1;
         for (int l = 0; l < nt; ++l) {
-            DQ_TRY(wrap_forward(l));
+            const int is = stack_idx(l), loc = local_l(l);
+            if (pg && loc >= 1) { DQ_TRY(wrap_forward_piggy(l, loc == 1 ? pg_eye : Pcur, Pnxt)); std::swap(Pcur, Pnxt); }   // P = B_{l-1} ... B_{l0}
+            else DQ_TRY(wrap_forward(l));
             DQ_TRY(local_update(l));
-            const int is = stack_idx(l);
-            if (local_l(l) == loc_l_end[is]) {
+            if (loc == loc_l_end[is]) {
                 DQ_TRY(launch_copy(mG(), Mat{Gtmp, nn}, nn, C, s));
-                Mat bb; DQ_TRY(Bbar(is, &bb));
+                Mat bb;
+                if (pg) {                                                                     // the block's last factor, whose slice has only now been updated
+                    if (loc == 0) DQ_TRY(launch_scale_rows(CMat(expK, nn), ev(l), Mat{Pnxt, nn}, n, C, s));
+                    else DQ_TRY(ctx.gemm(CMat(expK, nn), CMat(Pcur, nn), Mat{Pnxt, nn}, ev(l)));
+                    std::swap(Pcur, Pnxt); bb = Mat{Pcur, nn};
+                } else DQ_TRY(Bbar(is, &bb));
                 if (is == 0) DQ_TRY(ctx.to_ldr(bb, stk(0)));                                  // update_stack_forward :134-146
                 else DQ_TRY(ctx.mat_mul_ldr(bb, stk(is - 1), stk(is)));
                 gt_valid = false;                                                            // G is replaced below
@@ -574,13 +609,17 @@ struct Engine {
     int sweep_bwd() {
         int n_err = 0;
         DQ_HIP(hipMemsetAsync(err, 0, sizeof(double) * C * n_stack, s));
+        const bool pg = piggyback();
+        double* Pcur = bb0; double* Pnxt = bb1;
         for (int l = nt - 1; l >= 0; --l) {
             DQ_TRY(local_update(l));
-            DQ_TRY(wrap_backward(l));
             const int is = stack_idx(l);
+            if (pg) { DQ_TRY(wrap_backward_piggy(l, local_l(l) == loc_l_end[is] ? pg_eye : Pcur, Pnxt)); std::swap(Pcur, Pnxt); }   // P = B_hi ... B_l
+            else DQ_TRY(wrap_backward(l));
             if (local_l(l) == 0) {
                 DQ_TRY(launch_copy(mG(), Mat{Gtmp, nn}, nn, C, s));
-                Mat bb; DQ_TRY(Bbar(is, &bb));
+                Mat bb;
+                if (pg) bb = Mat{Pcur, nn}; else DQ_TRY(Bbar(is, &bb));
                 if (is == n_stack - 1) DQ_TRY(ctx.to_ldr(bb, stk(is)));                       // update_stack_backward :189-201
                 else DQ_TRY(ctx.ldr_mul_mat(stk(is + 1), bb, stk(is)));
                 gt_valid = false;
