@@ -75,6 +75,7 @@ int launch_build_expv(const int8_t* fields, long f_stride, int nt, int n, const 
                       double* expv, double* invexpv, long v_stride, int n_chains, hipStream_t s);
 // split d into 1/max(d,1) and min(d,1) (source/stablelinalg.cpp:100-108); also log-sum of max(d,1) into *logsum
 int launch_split_d(CVec d, Vec dl_inv, Vec ds, double* logsum, int n, int n_chains, hipStream_t s);
+int launch_split_d2(CVec d1, Vec dl1, Vec ds1, CVec d2, Vec dl2, Vec ds2, int n, int n_chains, hipStream_t s);   // two splits, one launch
 // equal-time observables of G (source/model.cpp:167-288) in displacement space (include/measurementh5.h:13-66):
 // out[chain][0..2] = density, doubleOcc, swave; out[chain][3 + dx_idx + L1*dy_idx] = chi_r.  accumulate: out += (else out =)
 int launch_measure_equal_time(CMat G, double* out, long out_stride, int L1, int L2, int accumulate, int n_chains, hipStream_t s);

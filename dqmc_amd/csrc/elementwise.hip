@@ -49,6 +49,25 @@ __global__ void split_d_kernel(CVec d, Vec dl_inv, Vec ds, double* logsum, int n
         if (threadIdx.x == 0) logsum[c] = red[0];
     }
 }
+// two D splits in one launch (blockIdx.x picks the vector): inv_I_plus_ldr_mul_ldr needs both of its factors' splits, and a launch is
+// ~4.5 us whatever it does
+__global__ void split_d2_kernel(CVec d1, Vec dl1, Vec ds1, CVec d2, Vec dl2, Vec ds2, int n) {
+    const int c = blockIdx.y;
+    const double* dd = blockIdx.x ? d2.at(c) : d1.at(c);
+    double* dl = blockIdx.x ? dl2.at(c) : dl1.at(c);
+    double* ds = blockIdx.x ? ds2.at(c) : ds1.at(c);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const double v = dd[i];
+        const bool large = v >= 1.0;
+        dl[i] = large ? 1.0 / v : 1.0;
+        ds[i] = large ? 1.0 : v;
+    }
+}
+int launch_split_d2(CVec d1, Vec dl1, Vec ds1, CVec d2, Vec dl2, Vec ds2, int n, int n_chains, hipStream_t s) {
+    hipLaunchKernelGGL(split_d2_kernel, dim3(2, n_chains), dim3(256), 0, s, d1, dl1, ds1, d2, dl2, ds2, n);
+    DQ_HIP(hipGetLastError());
+    return 0;
+}
 int launch_split_d(CVec d, Vec dl_inv, Vec ds, double* logsum, int n, int n_chains, hipStream_t s) {
     hipLaunchKernelGGL(split_d_kernel, dim3(1, n_chains), dim3(256), 0, s, d, dl_inv, ds, logsum, n);
     DQ_HIP(hipGetLastError());

@@ -193,8 +193,7 @@ struct Ctx {
     }
     // stablelinalg::inv_I_plus_ldr_mul_ldr (source/stablelinalg.cpp:128-158)   (uses T0..T3, V0..V3)
     int inv_I_plus_ldr_mul_ldr(LdrRef F1, LdrRef F2, Mat G) {
-        DQ_TRY(launch_split_d(F1.d, V(0), V(1), nullptr, n, C, stream));               // 1/D1l, D1s
-        DQ_TRY(launch_split_d(F2.d, V(2), V(3), nullptr, n, C, stream));               // 1/D2l, D2s
+        DQ_TRY(launch_split_d2(F1.d, V(0), V(1), F2.d, V(2), V(3), n, C, stream));     // 1/D1l, D1s | 1/D2l, D2s
         DQ_TRY(r_inverse_scaled(F2, V(2), T(1), T(0)));                                 // X = R2^-1 diag(1/D2l)
         DQ_TRY(gemm(F1.L, T(1), T(2), V(0), CVec(), CVec(), 1));                        // TermA = diag(1/D1l) L1^T X
         DQ_TRY(gemm(F1.R, F2.L, T(2), V(1), CVec(), V(3), 0, 1));                       // M = TermA + diag(D1s) R1 L2 diag(D2s)
@@ -587,7 +586,7 @@ struct Engine {
             else DQ_TRY(wrap_forward(l));
             DQ_TRY(local_update(l));
             if (loc == loc_l_end[is]) {
-                DQ_TRY(launch_copy(mG(), Mat{Gtmp, nn}, nn, C, s));
+                std::swap(G, Gtmp);                                                          // the wrapped G is kept for check_error, the stabilised one is written into the other buffer (no copy)
                 Mat bb;
                 if (pg) {                                                                     // the block's last factor, whose slice has only now been updated
                     if (loc == 0) DQ_TRY(launch_scale_rows(CMat(expK, nn), ev(l), Mat{Pnxt, nn}, n, C, s));
@@ -617,7 +616,7 @@ struct Engine {
             if (pg) { DQ_TRY(wrap_backward_piggy(l, local_l(l) == loc_l_end[is] ? pg_eye : Pcur, Pnxt)); std::swap(Pcur, Pnxt); }   // P = B_hi ... B_l
             else DQ_TRY(wrap_backward(l));
             if (local_l(l) == 0) {
-                DQ_TRY(launch_copy(mG(), Mat{Gtmp, nn}, nn, C, s));
+                std::swap(G, Gtmp);
                 Mat bb;
                 if (pg) bb = Mat{Pcur, nn}; else DQ_TRY(Bbar(is, &bb));
                 if (is == n_stack - 1) DQ_TRY(ctx.to_ldr(bb, stk(is)));                       // update_stack_backward :189-201

@@ -149,7 +149,7 @@ def _house_apply(Yw, j, p):
     Yw[j:, :] -= tau * np.outer(v, v @ Yw[j:, :])
 
 
-def qr_sketch_lookahead(M, b=16, sr=48, stats=None):
+def qr_sketch_lookahead(M, b=16, sr=48, stats=None, guard=0.0):
     """qr_sketch with the selection taken OFF the critical path: the pivots of panel k + 1 are chosen from the sketch of the matrix
     BEFORE panel k's update -- Y_k = Omega . A_k is fresh, the b known pivots of panel k are eliminated from it first (forced steps),
     and b greedy steps on the remaining sr - b rows pick panel k + 1 (Duersch & Gu: the residual block of the sketch after b
@@ -178,14 +178,23 @@ def qr_sketch_lookahead(M, b=16, sr=48, stats=None):
             for j, p in enumerate(cur):
                 live[p] = False
                 _house_apply(Yw, j, p)
-        # greedy continuation: the pivots of the NEXT panel
+        # greedy continuation: the pivots of the NEXT panel.  guard > 0: a winner whose sketch residual has fallen below guard x its
+        # sketch norm before the elimination carries no digits any more (the elimination happened in sketch space, in floating point):
+        # the look-ahead is abandoned and the next panel selects from ITS fresh sketch (nxt = None)
         nb2 = min(b, nc - bb)
         nx = []
+        n0 = np.einsum("ij,ij->j", Y, Y)
+        ok = True
         for j in range(bb, bb + nb2):
             nr = np.where(live, np.einsum("ij,ij->j", Yw[j:], Yw[j:]), -1.0)
-            p = int(np.argmax(nr)); nx.append(p); live[p] = False
+            p = int(np.argmax(nr))
+            if guard > 0 and nr[p] < (guard * guard) * n0[p]:          # the best candidate's residual is below the noise of its own elimination
+                ok = False; break
+            nx.append(p); live[p] = False
             _house_apply(Yw, j, p)
-        nxt = [cols[p] for p in nx] if nx else None
+        if stats is not None:
+            stats.append(1 if (ok and nx) else 0)
+        nxt = [cols[p] for p in nx] if (nx and ok) else None
         _apply_panel(A, k, bb, perm, cur, Qs, False)
         k += bb
     return _finish(A, k, perm, Qs)

@@ -20,6 +20,7 @@ from oracle import numpy_ref as nr                          # noqa: E402
 from oracle import panel_qr as pq                           # noqa: E402
 
 QUAL = []
+LA_STATS = []
 
 
 def wrap(fn):
@@ -47,12 +48,16 @@ VARIANTS = {
     "lookahead_b16_sr48": lambda M: pq.qr_sketch_lookahead(M, 16, 48),
     "lookahead_b16_sr40": lambda M: pq.qr_sketch_lookahead(M, 16, 40),
     "lookahead_b16_sr64": lambda M: pq.qr_sketch_lookahead(M, 16, 64),
+    "lookahead_b16_sr48_g1e-10": lambda M: pq.qr_sketch_lookahead(M, 16, 48, guard=1e-10, stats=LA_STATS),
+    "lookahead_b16_sr48_g1e-7": lambda M: pq.qr_sketch_lookahead(M, 16, 48, guard=1e-7, stats=LA_STATS),
     "normpanel_b32": lambda M: pq.qr_normpanel(M, 32),
     "normpanel_b16": lambda M: pq.qr_normpanel(M, 16),
 }
 
 
 def qual_line():
+    if LA_STATS:
+        print("      look-ahead selections usable: %d of %d panels" % (sum(LA_STATS), len(LA_STATS))); LA_STATS.clear()
     if not QUAL:
         return ""
     q = np.array(QUAL); QUAL.clear()
