@@ -327,10 +327,10 @@ __global__ __launch_bounds__(64 * NW) void qp_panel_kernel(Mat Am, QrWork w, int
         const int r0 = 64 * NW * b + 64 * wave + 16 * g;
         if (r0 == k) diag |= 1u << b;
         if (64 * NW * b + 64 * wave + 64 > k && 64 * NW * b + 64 * wave < n) blk_live |= 1u << b;   // wave-uniform: some row of the wave's 64 is in the panel
-        const double* src = A + (long)n * mycol + r0;
+        const double2* src = reinterpret_cast<const double2*>(A + (long)n * mycol + r0);      // 16 contiguous rows of one column: n and r0 are multiples of 16, so 16-byte pieces
         const bool rows_live = r0 >= k && r0 < n;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) a[b][i] = rows_live ? src[i] : 0.0;
+        for (int i = 0; i < 16; i += 2) { const double2 v = rows_live ? src[i >> 1] : double2{0.0, 0.0}; a[b][i] = v.x; a[b][i + 1] = v.y; }
         dpp_fence(a[b]);
     }
 #pragma unroll
@@ -350,17 +350,18 @@ __global__ __launch_bounds__(64 * NW) void qp_panel_kernel(Mat Am, QrWork w, int
         const int r0 = 64 * NW * b + 64 * wave + 16 * g;
         if (r0 >= k && r0 < n) {
             const bool isd = (diag >> b) & 1u;
-            double* dst = A + (long)n * mycol + r0;
-            double* vdst = Vp + (long)n * c + r0;
+            double2* dst = reinterpret_cast<double2*>(A + (long)n * mycol + r0);
+            double2* vdst = reinterpret_cast<double2*>(Vp + (long)n * c + r0);
+            double v[16], vc[16];
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const bool below = !isd || i > c;                         // strictly below the column's diagonal: the reflector tail
-                const double v = below ? a[b][i] * myscale : a[b][i];
-                const double vc = below ? v : (i == c ? 1.0 : 0.0);
-                dst[i] = v;
-                vdst[i] = vc;
-                VTp[(long)QP_B * (r0 + i) + c] = vc;
+                v[i] = below ? a[b][i] * myscale : a[b][i];
+                vc[i] = below ? v[i] : (i == c ? 1.0 : 0.0);
+                VTp[(long)QP_B * (r0 + i) + c] = vc[i];
             }
+#pragma unroll
+            for (int i = 0; i < 16; i += 2) { dst[i >> 1] = double2{v[i], v[i + 1]}; vdst[i >> 1] = double2{vc[i], vc[i + 1]}; }
         }
     }
     if (wave == 0 && g == 0) {
