@@ -6,7 +6,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from dqmc_amd.abi import DqmcLib
-lib = DqmcLib(os.path.join(ROOT, "scripts", "stamp_build", "libdqmc_hip_qpst.so"), "dqmc_")
+lib = DqmcLib(os.environ.get("DQMC_LIB", os.path.join(ROOT, "scripts", "stamp_build", "libdqmc_hip_qpst.so")), "dqmc_")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 rng = np.random.default_rng(3)
 M = rng.standard_normal((n, n)) * np.exp(rng.uniform(-6, 6, n))[None, :]
