@@ -1,0 +1,46 @@
+"""A longer Markov trajectory than the tests run: N sweeps of cfg 3 from the thermalised fixture on the HIP engine and on the CPU oracle
+(both of its dense back ends, one after the other: the back end is a process-wide switch) with the same random stream.  After EVERY
+sweep: are the HS fields identical, max|dG| GPU vs oracle (LAPACK back end) beside the CPU-vs-CPU difference of the two back ends on the
+same sweep, and max|G| (the 1e-10 bar is absolute on the fixture's O(10) entries; along a trajectory max|G(0,0)| wanders up to 1e3).
+usage: long_parity.py [sweeps] [cfg]      (DQMC_QR_PANEL=0 for the column-pivoted to_LDR)"""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import dqmc_amd
+from dqmc_amd import fixtures
+from oracle import oracle
+nsw = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+cfg = sys.argv[2] if len(sys.argv) > 2 else "cfg3"
+z, m, _ = fixtures.load(cfg + "_therm")
+hip = dqmc_amd.lib(); orc = oracle()
+rng = np.random.default_rng(4242)
+streams = [(m.random_stream(rng), m.random_stream(rng)) for _ in range(nsw)]
+
+
+def run(lib):
+    x = m.engine(lib); x.set_fields(z["fields"]); x.init()
+    out = []
+    for sf, sb in streams:
+        x.sweep_0_to_beta(*sf); x.sweep_beta_to_0(*sb)
+        out.append((x.get_G(), x.get_fields(), x.stats().max_err))
+    x.close()
+    return out
+
+
+t0 = time.time()
+have_lapack = orc.set_backend("lapack")
+ref = run(orc)
+orc.set_backend("builtin"); ref2 = run(orc) if have_lapack else ref
+gpu = run(hip)
+worst_abs = worst_rel = 0.0
+for sw in range(nsw):
+    G, f, we = gpu[sw]; Go, fo, weo = ref[sw]; Gb, fb, _ = ref2[sw]
+    dG = float(np.abs(G - Go).max()); fl = float(np.abs(Gb - Go).max()); gm = float(np.abs(Go).max())
+    same = np.array_equal(f, fo); same_cpu = np.array_equal(fb, fo)
+    worst_abs = max(worst_abs, dG); worst_rel = max(worst_rel, dG / max(1.0, gm))
+    print(f"sweep {sw + 1:3d}: fields gpu/cpu {'identical' if same else 'DIFFER'}, cpu/cpu {'identical' if same_cpu else 'DIFFER'}  max|dG| gpu-cpu {dG:.2e}  cpu-cpu {fl:.2e}  "
+          f"max|G| {gm:.1f}  rel {dG / max(1.0, gm):.1e}  wrap err (running max) gpu {we:.2e} cpu {weo:.2e}", flush=True)
+    if not same or not same_cpu:
+        print("trajectories separated (a borderline acceptance decided differently); later sweeps are not comparable"); break
+print(f"over {sw + 1} sweeps: worst max|dG| {worst_abs:.2e} absolute, {worst_rel:.2e} of max(1, max|G|)   [{time.time() - t0:.0f} s]")

@@ -745,6 +745,27 @@ def test_batched_engine_matches_single_chain_engines(hip):
         assert np.abs(Gb[c] - G1).max() < 1e-9 * max(1.0, np.abs(G1).max())
 
 
+def test_trajectory_of_several_sweeps(hip, orc):
+    """Six consecutive sweeps of cfg 3 from the thermalised fixture, device and oracle on the same stream: after EVERY sweep the HS fields
+    are identical (≈ 250 000 accepted flips in all) and G agrees to 1e-10 of max(1, max|G|).  Along a trajectory max|G(0,0)| leaves the
+    O(10) of the fixture (scripts/long_parity.py, 30 sweeps: up to 1.6e3, where two CPU evaluations differ by 1.2e-8 absolute themselves --
+    profiles/r04_long_parity_30sweeps_*.log), so the bound that travels is the relative one."""
+    z, m, _ = golden_util.load("cfg3_therm")
+    rng = np.random.default_rng(4242)
+    e = m.engine(hip); o = m.engine(orc)
+    for x in (e, o):
+        x.set_fields(z["fields"]); x.init()
+    for sw in range(6):
+        sf, sb = m.random_stream(rng), m.random_stream(rng)
+        for x in (e, o):
+            x.sweep_0_to_beta(*sf); x.sweep_beta_to_0(*sb)
+        Go = o.get_G()
+        assert np.array_equal(e.get_fields(), o.get_fields()), sw
+        assert np.abs(e.get_G() - Go).max() <= TOL * max(1.0, np.abs(Go).max()), (sw, np.abs(e.get_G() - Go).max(), np.abs(Go).max())
+    assert e.stats().n_accepted == o.stats().n_accepted
+    e.close()
+
+
 def test_solo_slice_kernel_from_224_chains_on(hip, orc):
     """From 224 chains per engine every chain walks AND flushes on its own CU (slice_solo_kernel: launch_update_slice, update.hip) --
     the deployment shape that fills the chip.  240 chains of the 4x4 lattice, each with its own fields and random stream, against 240
