@@ -15,12 +15,17 @@
 //              pivot column reaches the other 15 lanes of its DPP row by row_newbcast (v_fmac_f64_dpp), so the 15 dot products
 //              and the 15 updates of a step are 16 DPP-FMAs each; ONE fused reduction per step yields the dots, the squared
 //              norm of the pivot column's tail and the entries v_c^T v_j of the compact-WY factor T;
-//   update     A <- (I - V T V^T)^T A on the trailing columns, 16 columns per workgroup, v_mfma_f64_16x16x4_f64.
+//   update     A <- (I - V T V^T)^T A on the trailing columns, 16 columns per workgroup, v_mfma_f64_16x16x4_f64;
+//   form Q     Q = H_0 ... H_{n/16-1} from the same compact-WY factors (every panel's clean reflectors and T are kept), MFMA.
+//
+// n / 16 panels x (qp_panel_kernel, qp_update_kernel) + qp_formq_kernel: 575 us at n = 256 (qr_colown + formq_blocked: 892), 2.0 ms at
+// n = 576 (qr_coop: 4.26).  Where the time goes, and the forms that were measured and dropped (one persistent launch, a lane pair per
+// sketch column, 24 sketch rows, look-ahead selection): DESIGN.md section 5.
 //
 // Randomised panel pivoting (Duersch & Gu 2017; Martinsson, Quintana-Orti, Heavner, van de Geijn 2017).  The numpy statement
 // of exactly this algorithm is oracle/panel_qr.py::qr_sketch(b = 16, p = 16, sign = True, local_pivot = False); its effect on
 // G (cfg 3 thermalised sweep 3e-11 absolute, cfg 3 / cfg 5 i.i.d. <= 3e-11 relative; tournament pivoting and Gaussian sketches
-// beside it) is in profiles/r04_eval_panel_qr_numpy.log.
+// beside it) is in profiles/r04_eval_panel_qr_numpy.log; tests/test_panel_qr.py pins the numpy statements on the CPU.
 // Output format = the other QRCP kernels': reflectors and R0 in place in A WITHOUT column swaps, tau, jpvt (formq_* and
 // assemble_r_kernel of qr.hip finish L, d, R).
 #include "common.h"
@@ -144,7 +149,7 @@ __device__ __forceinline__ void lds_barrier() {
 // ---- selection: step J of the column-pivoted QR of the sketch ----
 // A lane owns CPL columns, col_q = t + 64 NW q (q < CPL), each as QP_SEL registers: the workgroup stays at one wave per SIMD up to
 // n = 1024 (NW = 4, CPL = 4).  With one column per lane n = 576 needs 9-10 waves, three on a SIMD, and a step costs what the three
-// issue one after the other (44.3 us per panel against the figure in DESIGN for 3 waves x 3 columns).
+// issue one after the other (24-row selection: 44.3 us per panel against 38.3 for 3 waves x 3 columns).
 template <int J, int NW, int CPL>
 __device__ __forceinline__ void select_step(double (&y)[CPL][QP_SEL], unsigned& live, int t, int lane, int wave, PanelShared<NW>& sh) {
     constexpr int par = J & 1;
