@@ -109,6 +109,22 @@ def test_to_ldr_panel_on_strongly_graded_matrices(hip, n, kind):
     assert rmax <= PANEL_QUALITY and grade <= PANEL_QUALITY
 
 
+@pytest.mark.parametrize("n", [64, 256])
+def test_to_ldr_panel_shows_numerical_rank(hip, n):
+    """A matrix of numerical rank n / 2 (the other half of the spectrum 1e-13 below): the panel-pivoted factorisation puts the n / 2 large
+    diagonal entries first, the small ones last with the gap intact, and still reconstructs the matrix -- the property the stabilised
+    products live on.  (A column of d = 0 would divide by zero in R exactly as dgeqp3's does: not exercised.)"""
+    rng = np.random.default_rng(700 + n)
+    U = np.linalg.qr(rng.standard_normal((n, n)))[0]; V = np.linalg.qr(rng.standard_normal((n, n)))[0]
+    sv = np.concatenate([np.exp(rng.uniform(-2, 2, n // 2)), 1e-13 * np.exp(rng.uniform(-2, 2, n - n // 2))])
+    M = (U * sv[None, :]) @ V.T
+    L, d, R = hip.to_ldr(M)
+    assert np.abs(L.T @ L - np.eye(n)).max() < 1e-13 * n
+    assert np.abs(ldr_mat((L, d, R)) - M).max() < 1e-13 * n * np.abs(M).max()
+    assert d[:n // 2].min() > 1e9 * d[n // 2:].max()          # the gap of 1e13 survives to within the grading constants
+    assert max(ldr_quality((L, d[:n // 2], R[:n // 2]))) <= PANEL_QUALITY
+
+
 def test_to_ldr_column_pivoted_kernels_in_subprocess(hip):
     """DQMC_QR_PANEL=0 keeps dgeqp3's own pivot order at every size (qr_colown.hip, qr_coop.hip): the oracle's d, R and |L| element-wise."""
     import subprocess, sys
