@@ -114,7 +114,7 @@ def omega_sign(rows, n):
     return _OMEGA[key]
 
 
-def qr_sketch(M, b=32, p=8, local_pivot=True, sign=False):
+def qr_sketch(M, b=32, p=8, local_pivot=True, sign=False, cand=0):
     A = np.array(M, dtype=np.float64, copy=True)
     n = A.shape[0]
     perm = list(range(n)); Qs = []
@@ -123,16 +123,23 @@ def qr_sketch(M, b=32, p=8, local_pivot=True, sign=False):
         nc = n - k
         bb = min(b, nc)
         if nc <= bb:
-            cand = list(range(nc))
+            cand_cols = list(range(nc))
             if not local_pivot and nc > 1:
                 _, _, pg = sla.qr(A[k:, k:], pivoting=True, mode="economic")
-                cand = list(pg)
+                cand_cols = list(pg)
         else:
             Om = (omega_sign(b + p, n) if sign else omega(b + p, n))[:, k:]
             Y = Om @ A[k:, k:]
-            _, _, pg = sla.qr(Y, pivoting=True, mode="economic")
-            cand = list(pg[:bb])
-        _apply_panel(A, k, bb, perm, cand, Qs, local_pivot)
+            if cand and nc > cand:
+                # the greedy selection restricted to the `cand` columns of largest sketch norm (what ONE wave can hold, a column per lane:
+                # no cross-wave exchange per step); the others are left for later panels
+                top = np.argsort(-np.einsum("ij,ij->j", Y, Y), kind="stable")[:cand]
+                _, _, pg = sla.qr(Y[:, top], pivoting=True, mode="economic")
+                pg = top[pg]
+            else:
+                _, _, pg = sla.qr(Y, pivoting=True, mode="economic")
+            cand_cols = list(pg[:bb])
+        _apply_panel(A, k, bb, perm, cand_cols, Qs, local_pivot)
         k += bb
     return _finish(A, k, perm, Qs)
 

@@ -50,6 +50,8 @@ VARIANTS = {
     "lookahead_b16_sr64": lambda M: pq.qr_sketch_lookahead(M, 16, 64),
     "lookahead_b16_sr48_g1e-10": lambda M: pq.qr_sketch_lookahead(M, 16, 48, guard=1e-10, stats=LA_STATS),
     "lookahead_b16_sr48_g1e-7": lambda M: pq.qr_sketch_lookahead(M, 16, 48, guard=1e-7, stats=LA_STATS),
+    "sign_b16_p16_cand64": lambda M: pq.qr_sketch(M, 16, 16, local_pivot=False, sign=True, cand=64),
+    "sign_b16_p16_cand32": lambda M: pq.qr_sketch(M, 16, 16, local_pivot=False, sign=True, cand=32),
     "normpanel_b32": lambda M: pq.qr_normpanel(M, 32),
     "normpanel_b16": lambda M: pq.qr_normpanel(M, 16),
 }
