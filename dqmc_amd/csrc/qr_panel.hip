@@ -394,7 +394,7 @@ __global__ __launch_bounds__(64 * NW) void qp_panel_kernel(Mat Am, QrWork w, int
 // A wave keeps its row tiles (tile rt = wave + QP_UW ti, ti < TPW) in registers in the accumulator layout from the first load on: the same
 // registers are the B operand of W = V^T A (k-step s <-> row kk + 4 s of the tile: any partition of k works as long as V is fed the same
 // way), the accumulator of A - V W', and the B operand of the sketch product.
-constexpr int QP_UW = 8;
+constexpr int QP_UW = 8;      // waves per workgroup of the update / form-Q kernels (4: 6.7 / 45.9 us at n = 256 against 6.3 / 40.9; 16: 8.3 / 166)
 template <bool UPDATE, int TPW>
 __global__ __launch_bounds__(64 * QP_UW) void qp_update_kernel(Mat Am, QrWork w, int n, int k) {
     constexpr int YT = QP_SR / 16;
