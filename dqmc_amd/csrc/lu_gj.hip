@@ -27,6 +27,7 @@
 #include "common.h"
 #include "wave.h"
 #include <cstdlib>
+#include <utility>
 
 namespace dq {
 
@@ -175,150 +176,239 @@ __global__ __launch_bounds__(64) void gj_panel_kernel(CMat Am, int* rowpos_p, lo
     }
 }
 
+// After a multi-wave panel, one wave each: log|det P11| with the singularity flag, and the four 16 x 16 triangular inverses of the pivot block
+// (4 us when wave 0 did both, each upper-block step ending in an fp64 division: the sixteen reciprocals are formed once, in parallel).
+__device__ __forceinline__ void gj_panel_logdet(double (&LU)[GJ_NB][GJ_NB], double* logabsdet, int accumulate, int* info, int chain, int lane, int nbw, int k0, int s_sing) {
+    const double pv = lane < nbw ? fabs(LU[lane][lane]) : 1.0;
+    const double ls = wave_sum(log(pv));
+    if (lane == 0) {
+        if (logabsdet) logabsdet[chain] = ((accumulate || k0 > 0) ? logabsdet[chain] : 0.0) + ls;
+        if (info && (s_sing || !(ls == ls))) atomicOr(info, 1);
+    }
+}
+template <int... Js>
+__device__ __forceinline__ void gj_tri_steps(double (&x)[16], const double* T0, int sg, int cc, bool up, bool hi, double rd, std::integer_sequence<int, Js...>) {
+    auto step = [&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        double s0 = (j == cc) ? 1.0 : 0.0, s1 = 0.0;
+#pragma unroll
+        for (int m = 0; m < j; ++m) {
+            const double tt = T0[sg * (j * 32 + m)];
+            if (m & 1) s1 = fma(-tt, x[m], s1); else s0 = fma(-tt, x[m], s0);
+        }
+        const double s = s0 + s1;
+        // 1 / U[base + 15 - j][base + 15 - j] sits in lane base + 15 - j (base = 0 or 16)
+        const double r0 = readlane_f64(rd, 15 - j), r1 = readlane_f64(rd, 31 - j);
+        x[j] = up ? s * (hi ? r1 : r0) : s;
+    };
+    (step(std::integral_constant<int, Js>{}), ...);
+}
+__device__ __forceinline__ void gj_panel_tri_inverses(double (&LU)[GJ_NB][GJ_NB], double* tinv, int lane) {
+    // one column per lane (lane = 16 * block + column): unit-lower blocks by forward substitution, upper blocks by the same recurrence on
+    // the index-reversed block
+    const int blk = lane >> 4, c = lane & 15;
+    const bool up = blk >= 2;
+    const int base = (blk & 1) * 16;
+    const double* T0 = &LU[0][0] + (up ? (base + 15) * 33 : base * 33);
+    const int sg = up ? -1 : 1;
+    const int cc = up ? 15 - c : c;
+    const double rd = 1.0 / LU[lane & 31][lane & 31];
+    double x[16];
+    gj_tri_steps(x, T0, sg, cc, up, (blk & 1) != 0, rd, std::make_integer_sequence<int, 16>{});
+    double* out = tinv + GJ_NB * GJ_NB + 256 * blk + 16 * c;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) out[up ? 15 - j : j] = x[j];
+}
+
+#ifdef DQ_GJ_STAMPS
+// diagnostic build only (scripts/gj_stamps.py): where a step's time goes; s_memtime counts 100 MHz ticks
+#define GST(i) { unsigned long long t_; asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); gst[i] += t_ - gprev; gprev = t_; }
+#define GST_ARGS , unsigned long long (&gst)[8], unsigned long long& gprev
+#define GST_PASS , gst, gprev
+#else
+#define GST(i)
+#define GST_ARGS
+#define GST_PASS
+#endif
 // ---- multi-wave panel: one row per lane, W = ceil(n / 64) waves (one per SIMD) ------------------------------------------------
 // The single-wave kernel above is bound by instruction issue (one wave, ~12 k instructions).  Here every wave owns 64 rows, so a
 // step costs a quarter of the FMAs per wave, at the price of one workgroup barrier per step: each wave finds its own best row,
 // and its candidate lane publishes {key, lane} and the row's live part (columns >= J) into the wave's LDS slot BEFORE the global
 // winner is known; after the barrier every wave reads the W keys, picks the winner (largest |a|, lowest wave on ties) and reads the
 // pivot row from the winner's slot.  Slots are double-buffered on the parity of J (a wave can be at most one step ahead).
-template <int J, int NW>
-__device__ __forceinline__ void gj_step_mw(double (&a)[GJ_NB], bool& live, int& mypos, int& myperm, bool& singular, int lane, int wave, int nw, int k0,
-                                           double (*slot_row)[NW][GJ_NB + 2], unsigned long long (*slot_key)[NW]) {
+template <int J, int NW, int RPL>
+__device__ __forceinline__ void gj_step_mw(double (&a)[RPL][GJ_NB], unsigned& live, int (&mypos)[RPL], int& myperm, bool& singular, int lane, int wave, int k0,
+                                           double (*slot_row)[NW][GJ_NB + 2], unsigned long long (*slot_key)[(NW + 1) & ~1] GST_ARGS) {
     constexpr int PAR = J & 1;
     constexpr int C0 = J & ~1;
-    // every lane's reciprocal of its own candidate element, off the critical path (dgetf2 scales by the reciprocal pivot as
+    GST(0)
+    // this lane's best row: strict comparisons keep the lowest slot (= the lowest row) on a tie
+    // (the values pass through an empty asm: a select between a[0][J], a[1][J], ... is otherwise turned into a load at a[bs][J], and a
+    // dynamically indexed array lives in scratch)
+    double aj = a[0][J]; int bs = 0;
+    if (RPL > 1) asm volatile("" : "+v"(aj));
+    unsigned long long key = (live & 1u) ? ((unsigned long long)__double_as_longlong(fabs(aj)) | 1ULL) : 0ULL;
+#pragma unroll
+    for (int q = 1; q < RPL; ++q) {
+        double v = a[q][J];
+        asm volatile("" : "+v"(v));
+        const unsigned long long kq = ((live >> q) & 1u) ? ((unsigned long long)__double_as_longlong(fabs(v)) | 1ULL) : 0ULL;
+        if (kq > key) { key = kq; aj = v; bs = q; }
+    }
+    // the reciprocal of the lane's own candidate element, off the critical path (dgetf2 scales by the reciprocal pivot as
     // well): v_rcp_f64 + two Newton steps; the winner's value travels with its row
-    double rme = __builtin_amdgcn_rcp(a[J]);
-    rme = fma(fma(-a[J], rme, 1.0), rme, rme);
-    rme = fma(fma(-a[J], rme, 1.0), rme, rme);
-    const unsigned long long key = live ? ((unsigned long long)__double_as_longlong(fabs(a[J])) | 1ULL) : 0ULL;
+    double rme = __builtin_amdgcn_rcp(aj);
+    rme = fma(fma(-aj, rme, 1.0), rme, rme);
+    rme = fma(fma(-aj, rme, 1.0), rme, rme);
     const unsigned hi = (unsigned)(key >> 32), lo = (unsigned)key;
     const unsigned m1 = wave_max_u32(hi);
     const unsigned m2 = wave_max_u32(hi == m1 ? lo : 0u);
-    const unsigned long long winners = __ballot(hi == m1 && lo == m2 && live);
+    const unsigned long long winners = __ballot(hi == m1 && lo == m2 && key != 0ULL);
     const int cl = winners ? (int)__builtin_ctzll(winners) : 0;
+    GST(1)
     if (lane == cl) {                                     // this wave's candidate
 #pragma unroll
-        for (int c = C0; c < GJ_NB; c += 2) *reinterpret_cast<double2*>(&slot_row[PAR][wave][c]) = make_double2(a[c], a[c + 1]);
+        for (int q = 0; q < RPL; ++q) {
+            if (bs == q) {                                // one of the RPL store sequences runs (the row index is a register name)
+#pragma unroll
+                for (int c = C0; c < GJ_NB; c += 2) *reinterpret_cast<double2*>(&slot_row[PAR][wave][c]) = make_double2(a[q][c], a[q][c + 1]);
+            }
+        }
         slot_row[PAR][wave][GJ_NB] = rme;
-        // key: |a| with its low 9 bits replaced by {non-empty marker, lane}; waves compare bits 8 and up (44 mantissa bits)
-        slot_key[PAR][wave] = winners ? ((((unsigned long long)m1 << 32) | m2) & ~0xFFULL) | (unsigned long long)cl | 0x100ULL : 0ULL;
+        // key: |a| with its low 9 bits replaced by {non-empty marker, slot, lane}; waves compare bits 9 and up (43 mantissa bits)
+        slot_key[PAR][wave] = winners ? ((((unsigned long long)m1 << 32) | m2) & ~0x1FFULL) | (unsigned long long)(cl | (bs << 6)) | 0x100ULL : 0ULL;
     }
+    GST(2)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    GST(3)
     // all keys in ONE LDS round trip (slots of absent waves stay 0 = "no candidate"): reading them under `w < nw` branches
     // made each key its own dependent round trip, ~450 clk per step
-    ulonglong2 kp[NW / 2];
+    constexpr int NWK = (NW + 1) & ~1;
+    ulonglong2 kp[NWK / 2];
 #pragma unroll
-    for (int q = 0; q < NW / 2; ++q) kp[q] = *reinterpret_cast<const ulonglong2*>(&slot_key[PAR][2 * q]);
+    for (int q = 0; q < NWK / 2; ++q) kp[q] = *reinterpret_cast<const ulonglong2*>(&slot_key[PAR][2 * q]);
     unsigned long long best = kp[0].x; int pw = 0;
-    if ((kp[0].y >> 8) > (best >> 8)) { best = kp[0].y; pw = 1; }
+    if ((kp[0].y >> 9) > (best >> 9)) { best = kp[0].y; pw = 1; }
 #pragma unroll
-    for (int q = 1; q < NW / 2; ++q) {                    // strict: the lowest wave wins a tie (= the lowest row, as dgetf2's idamax)
-        if ((kp[q].x >> 8) > (best >> 8)) { best = kp[q].x; pw = 2 * q; }
-        if ((kp[q].y >> 8) > (best >> 8)) { best = kp[q].y; pw = 2 * q + 1; }
+    for (int q = 1; q < NWK / 2; ++q) {                   // strict: the lowest wave wins a tie
+        if ((kp[q].x >> 9) > (best >> 9)) { best = kp[q].x; pw = 2 * q; }
+        if ((kp[q].y >> 9) > (best >> 9)) { best = kp[q].y; pw = 2 * q + 1; }
     }
-    const int pl = (int)(best & 0xFFULL);
+    const int pl = (int)(best & 0x3FULL), ps = (int)((best >> 6) & 3ULL);
+    GST(4)
     double prow[GJ_NB - C0];
 #pragma unroll
     for (int c = C0; c < GJ_NB; c += 2) { const double2 v = *reinterpret_cast<const double2*>(&slot_row[PAR][pw][c]); prow[c - C0] = v.x; prow[c + 1 - C0] = v.y; }
     const double r = slot_row[PAR][pw][GJ_NB];
-    if (lane == J && wave == 0) myperm = pl + 64 * pw;
-    if (wave == pw && lane == pl) { live = false; mypos = k0 + J; }
+    GST(5)
+    if (lane == J && wave == 0) myperm = pl + 64 * pw + 64 * NW * ps;
+    const bool mine = wave == pw && lane == pl;
     singular = singular || !(fabs(prow[J - C0]) > 0.0);
-    // branch-free: dead rows (earlier pivots, rows >= n) run the FMAs with l = 0, so the next step's pivot search can be
-    // scheduled into them
-    const double l = live ? a[J] * r : 0.0;
-    a[J] = live ? l : a[J];
 #pragma unroll
-    for (int c = J + 1; c < GJ_NB; ++c) a[c] = fma(-l, prow[c - C0], a[c]);
+    for (int q = 0; q < RPL; ++q) {
+        if (mine && ps == q) { live &= ~(1u << q); mypos[q] = k0 + J; }
+        // branch-free: dead rows (earlier pivots, rows >= n) run the FMAs with l = 0, so the next step's pivot search can be
+        // scheduled into them
+        const bool lv = (live >> q) & 1u;
+        const double l = lv ? a[q][J] * r : 0.0;
+        a[q][J] = lv ? l : a[q][J];
+#pragma unroll
+        for (int c = J + 1; c < GJ_NB; ++c) a[q][c] = fma(-l, prow[c - C0], a[q][c]);
+    }
+    GST(6)
 }
-template <int J, int NW>
+template <int J, int NW, int RPL>
 struct GjStepsMW {
-    static __device__ __forceinline__ void run(double (&a)[GJ_NB], bool& live, int& mypos, int& myperm, bool& singular, int lane, int wave, int nw, int nbw, int k0,
-                                               double (*slot_row)[NW][GJ_NB + 2], unsigned long long (*slot_key)[NW]) {
-        if (J < nbw) gj_step_mw<J, NW>(a, live, mypos, myperm, singular, lane, wave, nw, k0, slot_row, slot_key);      // workgroup-uniform
-        GjStepsMW<J + 1, NW>::run(a, live, mypos, myperm, singular, lane, wave, nw, nbw, k0, slot_row, slot_key);
+    static __device__ __forceinline__ void run(double (&a)[RPL][GJ_NB], unsigned& live, int (&mypos)[RPL], int& myperm, bool& singular, int lane, int wave, int nbw, int k0,
+                                               double (*slot_row)[NW][GJ_NB + 2], unsigned long long (*slot_key)[(NW + 1) & ~1] GST_ARGS) {
+        if (J < nbw) gj_step_mw<J, NW, RPL>(a, live, mypos, myperm, singular, lane, wave, k0, slot_row, slot_key GST_PASS);      // workgroup-uniform
+        GjStepsMW<J + 1, NW, RPL>::run(a, live, mypos, myperm, singular, lane, wave, nbw, k0, slot_row, slot_key GST_PASS);
     }
 };
-template <int NW>
-struct GjStepsMW<GJ_NB, NW> {
-    static __device__ __forceinline__ void run(double (&)[GJ_NB], bool&, int&, int&, bool&, int, int, int, int, int, double (*)[NW][GJ_NB + 2], unsigned long long (*)[NW]) {}
+template <int NW, int RPL>
+struct GjStepsMW<GJ_NB, NW, RPL> {
+    static __device__ __forceinline__ void run(double (&)[RPL][GJ_NB], unsigned&, int (&)[RPL], int&, bool&, int, int, int, int, double (*)[NW][GJ_NB + 2],
+                                               unsigned long long (*)[(NW + 1) & ~1] GST_ARGS) {}
 };
-// NW: most waves the workgroup may have (one matrix row per lane): 4 for n <= 256, 10 for n <= 640, 16 for n <= 1024
-template <int NW>
-
+// NW waves (the most the workgroup may have), RPL matrix rows per lane: row t + 64 NW q is slot q of thread t.  One wave per SIMD up to n = 768
+// (<4, 1> n <= 256, <4, 2> <= 512, <3, 3> <= 576, <4, 3> <= 768), two beyond (<8, 2>): with one row per lane n = 576 took 9 waves, three on
+// a SIMD, and a step cost what the three issue one after the other plus nine single-lane row publishes instead of three.
+template <int NW, int RPL>
 __global__ __launch_bounds__(64 * NW) void gj_panel_mw_kernel(CMat Am, int* rowpos_p, long rowpos_stride, int* perm_p, long perm_stride, double* tinv_p,
                                                           double* logabsdet, int accumulate, int* info, int n, int k0) {
+    constexpr int NWK = (NW + 1) & ~1;
     __shared__ __attribute__((aligned(16))) double LU[GJ_NB][GJ_NB];
     __shared__ __attribute__((aligned(16))) double slot_row[2][NW][GJ_NB + 2];     // row | reciprocal of its pivot element
-    __shared__ __attribute__((aligned(16))) unsigned long long slot_key[2][NW];
+    __shared__ __attribute__((aligned(16))) unsigned long long slot_key[2][NWK];
     __shared__ int s_sing;
-    static_assert(NW % 2 == 0, "keys are read in pairs");
+    static_assert(RPL <= 4, "two key bits name the slot");
     const int chain = blockIdx.y;
     const double* __restrict__ A = Am.at(chain);
     int* rowpos = rowpos_p + (long)chain * rowpos_stride;
     int* perm = perm_p + (long)chain * perm_stride;
     double* tinv = tinv_p + (long)chain * 2 * GJ_NB * GJ_NB;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, nw = blockDim.x >> 6;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+#ifdef DQ_GJ_STAMPS
+    unsigned long long gentry;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(gentry) :: "memory");
+#endif
     const int nbw = min(GJ_NB, n - k0);
-    const int r = t;
-    bool live = r < n && (k0 == 0 ? true : rowpos[r] < 0);
-    int mypos = -1, myperm = 0; bool singular = false;
-    double a[GJ_NB];
+    unsigned live = 0u;
+    int mypos[RPL], myperm = 0; bool singular = false;
+    double a[RPL][GJ_NB];
 #pragma unroll
-    for (int c = 0; c < GJ_NB; ++c) a[c] = (live && c < nbw) ? A[r + (long)n * (k0 + c)] : 0.0;
+    for (int q = 0; q < RPL; ++q) {
+        const int r = t + 64 * NW * q;
+        const bool lv = r < n && (k0 == 0 ? true : rowpos[r < n ? r : 0] < 0);
+        live |= lv ? (1u << q) : 0u;
+        mypos[q] = -1;
+#pragma unroll
+        for (int c = 0; c < GJ_NB; ++c) a[q][c] = (lv && c < nbw) ? A[r + (long)n * (k0 + c)] : 0.0;
+    }
     for (int e = t; e < GJ_NB * GJ_NB; e += blockDim.x) (&LU[0][0])[e] = ((e >> 5) == (e & 31)) ? 1.0 : 0.0;   // identity padding for nbw < 32
     if (t == 0) s_sing = 0;
-    if (t < 2 * NW) (&slot_key[0][0])[t] = 0ULL;          // waves that do not exist never publish: their keys stay "no candidate"
+    if (t < 2 * NWK) (&slot_key[0][0])[t] = 0ULL;         // waves that do not exist never publish: their keys stay "no candidate"
     __syncthreads();
 
-    GjStepsMW<0, NW>::run(a, live, mypos, myperm, singular, lane, wave, nw, nbw, k0, slot_row, slot_key);
+#ifdef DQ_GJ_STAMPS
+    unsigned long long gst[8] = {0, 0, 0, 0, 0, 0, 0, 0}, gprev, gstart;
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(gprev) :: "memory"); gstart = gprev;
+#endif
+    GjStepsMW<0, NW, RPL>::run(a, live, mypos, myperm, singular, lane, wave, nbw, k0, slot_row, slot_key GST_PASS);
+#ifdef DQ_GJ_STAMPS
+    if (t == 0 && k0 == 0 && blockIdx.y == 0)
+        printf("gj panel k0=0 n=%d, %d waves x %d rows per lane, clocks over %d steps (each segment includes one stamp, ~130): (loop) %llu | search %llu | publish %llu | barrier %llu | keys %llu | row %llu | fma %llu | total %llu\n",
+               n, (int)(blockDim.x >> 6), RPL, nbw, gst[0], gst[1], gst[2], gst[3], gst[4], gst[5], gst[6], gprev - gstart);
+#endif
 
     __syncthreads();                                     // identity fill done everywhere before the pivot rows overwrite theirs
-    if (r < n) { if (k0 == 0) rowpos[r] = mypos; else if (mypos >= 0) rowpos[r] = mypos; }
-    if (mypos >= 0) {
-        double* dst = &LU[mypos - k0][0];
 #pragma unroll
-        for (int c = 0; c < GJ_NB; c += 2) *reinterpret_cast<double2*>(dst + c) = make_double2(a[c], a[c + 1]);
+    for (int q = 0; q < RPL; ++q) {
+        const int r = t + 64 * NW * q;
+        if (r < n) { if (k0 == 0) rowpos[r] = mypos[q]; else if (mypos[q] >= 0) rowpos[r] = mypos[q]; }
+        if (mypos[q] >= 0) {
+            double* dst = &LU[mypos[q] - k0][0];
+#pragma unroll
+            for (int c = 0; c < GJ_NB; c += 2) *reinterpret_cast<double2*>(dst + c) = make_double2(a[q][c], a[q][c + 1]);
+        }
     }
     if (wave == 0 && lane < nbw) perm[k0 + lane] = myperm;
     if (singular && lane == 0) s_sing = 1;
     __syncthreads();
     for (int e = t; e < GJ_NB * GJ_NB; e += blockDim.x) tinv[e] = (&LU[0][0])[e];
-    if (wave == 0) {
-        {                                                // log|det P11| and singularity check
-            const double pv = lane < nbw ? fabs(LU[lane][lane]) : 1.0;
-            const double ls = wave_sum(log(pv));
-            if (lane == 0) {
-                if (logabsdet) logabsdet[chain] = ((accumulate || k0 > 0) ? logabsdet[chain] : 0.0) + ls;
-                if (info && (s_sing || !(ls == ls))) atomicOr(info, 1);
-            }
-        }
-        // the four 16 x 16 triangular inverses, one column per lane (see gj_panel_kernel)
-        const int blk = lane >> 4, c = lane & 15;
-        const bool up = blk >= 2;
-        const int base = (blk & 1) * 16;
-        const double* T0 = &LU[0][0] + (up ? (base + 15) * 33 : base * 33);
-        const int sg = up ? -1 : 1;
-        const int cc = up ? 15 - c : c;
-        double x[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            double s0 = (j == cc) ? 1.0 : 0.0, s1 = 0.0;
-#pragma unroll
-            for (int m = 0; m < j; ++m) {
-                const double tt = T0[sg * (j * 32 + m)];
-                if (m & 1) s1 = fma(-tt, x[m], s1); else s0 = fma(-tt, x[m], s0);
-            }
-            const double s = s0 + s1;
-            x[j] = up ? s / T0[sg * (j * 33)] : s;
-        }
-        double* out = tinv + GJ_NB * GJ_NB + 256 * blk + 16 * c;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) out[up ? 15 - j : j] = x[j];
-    }
+#ifdef DQ_GJ_STAMPS
+    unsigned long long gmid;
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(gmid) :: "memory");
+#endif
+    if (wave == 0) gj_panel_tri_inverses(LU, tinv, lane);
+    else if (wave == 1) gj_panel_logdet(LU, logabsdet, accumulate, info, chain, lane, nbw, k0, s_sing);
+#ifdef DQ_GJ_STAMPS
+    unsigned long long gend;
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(gend) :: "memory");
+    if (t == 0 && k0 == 0 && blockIdx.y == 0) printf("   prologue %llu | steps %llu | LU hand-over (+ printf) %llu | epilogue %llu\n", gstart - gentry, gprev - gstart, gmid - gprev, gend - gmid);
+#endif
 }
 
 // MFMA operand convention (v_mfma_f64_16x16x4_f64, lane = (r16, kk) = (lane & 15, lane >> 4)):
@@ -451,10 +541,12 @@ int launch_gj_solve(Mat A, Mat B, Mat X, Mat SA, double* tinv, int* perm, long p
     if (n > 1024) { set_error("gj_solve supports n <= 1024"); return -1; }
     for (int k0 = 0; k0 < n; k0 += GJ_NB) {
         const dim3 pg(1, n_chains);
-        const dim3 pb(((n + 63) / 64) * 64);
-        if (n > 640) hipLaunchKernelGGL((gj_panel_mw_kernel<16>), pg, pb, 0, s, CMat(A), rowpos, rowpos_stride, perm, perm_stride, tinv, logabsdet, accumulate_logdet, info, n, k0);
-        else if (n > 256) hipLaunchKernelGGL((gj_panel_mw_kernel<10>), pg, pb, 0, s, CMat(A), rowpos, rowpos_stride, perm, perm_stride, tinv, logabsdet, accumulate_logdet, info, n, k0);
-        else if (n > 64) hipLaunchKernelGGL((gj_panel_mw_kernel<4>), pg, pb, 0, s, CMat(A), rowpos, rowpos_stride, perm, perm_stride, tinv, logabsdet, accumulate_logdet, info, n, k0);
+#define DQ_GJ_PANEL(NW, RPL) hipLaunchKernelGGL((gj_panel_mw_kernel<NW, RPL>), pg, dim3(RPL == 1 ? 64 * ((n + 63) / 64) : 64 * NW), 0, s, CMat(A), rowpos, rowpos_stride, perm, perm_stride, tinv, logabsdet, accumulate_logdet, info, n, k0)
+        if (n > 768) DQ_GJ_PANEL(8, 2);
+        else if (n > 576) DQ_GJ_PANEL(4, 3);
+        else if (n > 512) DQ_GJ_PANEL(3, 3);
+        else if (n > 256) DQ_GJ_PANEL(4, 2);
+        else if (n > 64) DQ_GJ_PANEL(4, 1);
         else hipLaunchKernelGGL((gj_panel_kernel<1>), pg, dim3(64), 0, s, CMat(A), rowpos, rowpos_stride, perm, perm_stride, tinv, logabsdet, accumulate_logdet, info, n, k0);      // n <= 64: one wave holds every row
         const int nbw = n - k0 < GJ_NB ? n - k0 : GJ_NB;
         const int nA = (n + 31) / 32, nS = k0 / 32;
@@ -462,6 +554,7 @@ int launch_gj_solve(Mat A, Mat B, Mat X, Mat SA, double* tinv, int* perm, long p
         hipLaunchKernelGGL(gj_update_kernel, dim3((nA + nS + 1) * (nCA + nCB), n_chains), dim3(256), 0, s, A, B, SA, X, (const int*)rowpos, rowpos_stride,
                            (const int*)perm, perm_stride, (const double*)tinv, n, k0, nA, nS, nCA);
     }
+#undef DQ_GJ_PANEL
     DQ_HIP(hipGetLastError());
     return 0;
 }
