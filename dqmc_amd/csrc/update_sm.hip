@@ -71,28 +71,32 @@ __device__ __forceinline__ double shfl_f64(double x, int src_lane) {
 }
 
 struct SmShared {
-    double* cols; double* rows;                 // [kd][ls]
-    int ls;
+    double* panels;                             // cols | rows of the current window, [kd_w][ls_w] each, re-laid-out per window (below)
+    long room;                                  // doubles available for the two panels
     double* diag0; double* dlt; double* rbv; double* ur; double* tl;
-    int* site; signed char* newf; int* acc_site;
+    int* site; signed char* newf; int* acc_site; int* posof;
 };
-__host__ __device__ inline size_t sm_fixed_bytes(int n) { return (size_t)n * 32 + 256 + (size_t)n * 4 + (((size_t)n + 7) & ~(size_t)7) + SM_KD * 4 + 64; }
-__host__ __device__ inline size_t sm_lds_bytes(int n, int kd) { return (size_t)2 * kd * sm_ls(n) * 8 + sm_fixed_bytes(n); }
-// window size the 160 KiB of LDS allow: A^T and B^T of the window are kd x n each
-__host__ __device__ inline int sm_pick_kd(int n) {
-    const long room = 160L * 1024 - (long)sm_fixed_bytes(n) - 256;
-    long kd = room / (16L * sm_ls(n));
+// LDS: the fixed part first, then the panels.  Within a window only the sites still to be visited are ever looked up, so the panels are
+// indexed by POSITION in the slice's visiting order relative to the window's first proposal (column q <-> position pos0 + q): a window that
+// starts at position pos0 needs n - pos0 columns, and the window size grows as the slice proceeds,
+//     kd_w = min(32, room / (2 ls_w)),   ls_w = sm_ls(n - pos0)
+// (n = 576: 15, 16, 17, 19, 21, 24, 28, 32, ... instead of 15 throughout: 10-11 windows per slice instead of 16, each ~27 us of hand-off).
+__host__ __device__ inline size_t sm_fixed_bytes(int n) { return (size_t)n * 32 + 256 + (size_t)n * 8 + (((size_t)n + 7) & ~(size_t)7) + SM_KD * 4 + 64; }
+__host__ __device__ inline long sm_room_doubles(int n) { return (160L * 1024 - 256 - (long)sm_fixed_bytes(n)) / 8; }
+__host__ __device__ inline size_t sm_lds_bytes(int n) { return sm_fixed_bytes(n) + (size_t)sm_room_doubles(n) * 8; }
+__host__ __device__ inline int sm_window_kd(long room, int ls) {
+    const long kd = room / (2L * ls);
     return (int)(kd > SM_KD ? SM_KD : kd < 1 ? 1 : kd);
 }
-__device__ __forceinline__ void sm_shared_init(SmShared& sh, unsigned char* smem, int n, int kd) {
-    sh.ls = sm_ls(n);
-    sh.cols = reinterpret_cast<double*>(smem);
-    sh.rows = sh.cols + kd * sh.ls;
-    sh.diag0 = sh.rows + kd * sh.ls;
+__device__ __forceinline__ void sm_shared_init(SmShared& sh, unsigned char* smem, int n) {
+    sh.diag0 = reinterpret_cast<double*>(smem);
     sh.dlt = sh.diag0 + n; sh.rbv = sh.dlt + n; sh.ur = sh.rbv + n; sh.tl = sh.ur + n;
     sh.site = reinterpret_cast<int*>(sh.tl + 32);
-    sh.newf = reinterpret_cast<signed char*>(sh.site + n);
+    sh.posof = sh.site + n;
+    sh.newf = reinterpret_cast<signed char*>(sh.posof + n);
     sh.acc_site = reinterpret_cast<int*>(sh.newf + ((n + 7) & ~7));
+    sh.panels = reinterpret_cast<double*>(smem + sm_fixed_bytes(n));
+    sh.room = sm_room_doubles(n);
 }
 
 // G[tt, site] (PC##q##_sl) and G[site, tt] (PR##q##_sl, from the transposed copy) of the 8 proposals of group gg for the thread's site
@@ -180,7 +184,7 @@ struct SmProf { unsigned long long t_pass = 0, t_acc = 0, t_dump = 0, t_hand = 0
 // Walks one window: from proposal `pos` until KD flips are pending or the slice is over; then writes A^T, B^T, C (the
 // flush's operands) and the accepted field changes to memory.  Returns the number of flips.
 template <int NS>
-__device__ __forceinline__ int sm_walk_window(const SmShared& sh, int& pos, int n, int kd, int t, const double* __restrict__ G,
+__device__ __forceinline__ int sm_walk_window(const SmShared& sh, int& pos, int n, int t, const double* __restrict__ G,
                                               const double* __restrict__ GT, const UpdateDesc& d, long slice_off, int chain, int8_t* fields_g,
                                               double* __restrict__ Ap, double* __restrict__ Bp, double* __restrict__ Cp, bool reload_diag SM_PROF_ARG) {
     const int lane = t & 63, wave = t >> 6, h = lane >> 5, m = lane & 31, r16 = lane & 15;
@@ -196,7 +200,15 @@ __device__ __forceinline__ int sm_walk_window(const SmShared& sh, int& pos, int 
     SM_DECL8(pcA); SM_DECL8(prA); SM_DECL8(pcB); SM_DECL8(prB); SM_DECL8(pcC); SM_DECL8(prC);   // prefetched G column / row elements of group (g % 3)
     const int tt0 = min(t, n - 1), tt1 = min(t + 256, n - 1), tt2 = min(t + 512, n - 1), tt3 = min(t + 768, n - 1);   // clamped site slots
     (void)tt1; (void)tt2; (void)tt3;
-    const int LS = sh.ls;
+    // this window's panels: columns <-> positions pos0, pos0 + 1, ... (the sites still to be visited)
+    const int pos0 = pos;
+    const int LS = sm_ls(n - pos0);
+    const int kd = sm_window_kd(sh.room, LS);
+    double* const cols = sh.panels;
+    double* const rows = sh.panels + (long)kd * LS;
+    // panel column of the thread's own sites (negative: visited before this window, never looked up again)
+    const int q0 = sh.posof[tt0] - pos0, q1 = sh.posof[tt1] - pos0, q2 = sh.posof[tt2] - pos0, q3 = sh.posof[tt3] - pos0;
+    (void)q1; (void)q2; (void)q3;
 #pragma unroll
     for (int e = 0; e < 16; ++e) { c0[e] = 0.0; c1[e] = 0.0; t0[e] = 0.0; t1[e] = 0.0; }
     int k = 0;
@@ -219,6 +231,12 @@ __device__ __forceinline__ int sm_walk_window(const SmShared& sh, int& pos, int 
         for (int s_ = 0; s_ < NS; ++s_) { const int tt = t + 256 * s_; if (tt < n) sh.diag0[tt] = dgl[s_]; }
         lds_barrier();
     }
+#define SM_SLOT(sl)                                                                                                                      \
+    if (t + 256 * sl < n) {                                                                                                              \
+        const double cv_ = gc##sl, rv_ = (t + 256 * sl == i) ? gr##sl - 1.0 : gr##sl;                                                    \
+        if (q##sl >= 0) { cols[k * LS + q##sl] = cv_; rows[k * LS + q##sl] = rv_; }                                                      \
+        st_coh(Ap + k * n + t + 256 * sl, cv_); st_coh(Bp + k * n + t + 256 * sl, rv_);                                                  \
+    }
 #define SM_GROUP(PCS, PRS, PCT, PRT)                                                                                                     \
     {                                                                                                                                    \
         SM_LOAD8(PCT, PRT, g + LEAD)                                                                                                     \
@@ -231,8 +249,8 @@ __device__ __forceinline__ int sm_walk_window(const SmShared& sh, int& pos, int 
             const int jme = sh.site[pme];                                                                                                \
             const int kc = max(k - 1, 0);                                                                                                \
             /* beta = rows[:, j] and alpha = cols[:, j] in broadcast layout (lane r of every 16-lane row: entries r and 16 + r), alpha_m own */ \
-            const int o_a = min(r16, kc) * LS + jme, o_b = min(16 + r16, kc) * LS + jme;                                              \
-            double be_a = sh.rows[o_a], be_b = sh.rows[o_b], al_a = sh.cols[o_a], al_b = sh.cols[o_b];                                   \
+            const int o_a = min(r16, kc) * LS + (pme - pos0), o_b = min(16 + r16, kc) * LS + (pme - pos0);                            \
+            double be_a = rows[o_a], be_b = rows[o_b], al_a = cols[o_a], al_b = cols[o_b];                                               \
             const double d0 = sh.diag0[jme], dl = sh.dlt[pme], rb = sh.rbv[pme], uu = sh.ur[pme];                                        \
             if (r16 >= k) { be_a = 0.0; al_a = 0.0; }                                                                                    \
             if (16 + r16 >= k) { be_b = 0.0; al_b = 0.0; }                                                                               \
@@ -271,11 +289,8 @@ __device__ __forceinline__ int sm_walk_window(const SmShared& sh, int& pos, int 
             /* slot k of A^T / B^T: the column and the row of G0 at the flipped site, every thread its own element */                   \
             double gc0, gr0, gc1, gr1, gc2, gr2, gc3, gr3;                                                                               \
             SM_PICK8(PCS, PRS)                                                                                                           \
-            /* V(i) -= 1 (source/model.cpp:135) */                                                                                       \
-            if (t < n) { sh.cols[k * LS + t] = gc0; sh.rows[k * LS + t] = (t == i) ? gr0 - 1.0 : gr0; }                                  \
-            if (NS > 1 && t + 256 < n) { sh.cols[k * LS + t + 256] = gc1; sh.rows[k * LS + t + 256] = (t + 256 == i) ? gr1 - 1.0 : gr1; } \
-            if (NS > 2 && t + 512 < n) { sh.cols[k * LS + t + 512] = gc2; sh.rows[k * LS + t + 512] = (t + 512 == i) ? gr2 - 1.0 : gr2; } \
-            if (NS > 3 && t + 768 < n) { sh.cols[k * LS + t + 768] = gc3; sh.rows[k * LS + t + 768] = (t + 768 == i) ? gr3 - 1.0 : gr3; } \
+            /* V(i) -= 1 (source/model.cpp:135).  LDS: the sites still to come, by position; memory: the whole column / row, the flush's operands */ \
+            SM_SLOT(0) if constexpr (NS > 1) SM_SLOT(1) if constexpr (NS > 2) SM_SLOT(2) if constexpr (NS > 3) SM_SLOT(3)                \
             if (t == 0) sh.acc_site[k] = p;                                                                                              \
             ++k;                                                                                                                         \
             lds_barrier();                                                                                                               \
@@ -298,10 +313,9 @@ __device__ __forceinline__ int sm_walk_window(const SmShared& sh, int& pos, int 
         }
     }
 #undef SM_GROUP
+#undef SM_SLOT
     SMX(unsigned long long td0; SMT(td0))
-    // ---- window end: A^T, B^T (from LDS) and C (from the registers of wave 0) leave the workgroup ----
-    for (int tt = t; tt < n; tt += 256)
-        for (int mm = 0; mm < k; ++mm) { st_coh(Ap + mm * n + tt, sh.cols[mm * LS + tt]); st_coh(Bp + mm * n + tt, sh.rows[mm * LS + tt]); }
+    // ---- window end: C (from the registers of wave 0) leaves the workgroup; A^T and B^T went to memory flip by flip ----
     if (wave == 0 && lane < 32) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) { st_coh(Cp + m * SM_KD + e, c0[e]); st_coh(Cp + m * SM_KD + 16 + e, c1[e]); }
@@ -324,29 +338,42 @@ static_assert(SM_KD == 32, "the sub-matrix walk keeps C as 2 x 16 register colum
 //   D1[nn][a] = sum_m C[m][nn] A^T[m][a]      two 16 x 16 accumulators (nn < 16, nn >= 16), 8 k-steps each
 //   G[a][b]  += sum_nn D1[nn][a] B^T[nn][b]    accumulator rows <-> b: D1's registers are the B operands
 //   GT[b][a] += the same                      accumulator rows <-> a: D1's registers are the A operands
-__device__ __forceinline__ void sm_flush_tile(double* __restrict__ G, double* __restrict__ GT, const double* __restrict__ Ap,
-                                              const double* __restrict__ Bp, const double* __restrict__ Cp, int a0, int b0, int n, int k, int lane) {
+// Loads and arithmetic are separate calls: a workgroup that owns two tiles (n = 576) requests the operands of both before it computes
+// on the first -- one memory round trip per window instead of two in a row.
+struct SmFlushOps {
+    double av[8], bv[8], gv[4], gt[4];
+    int a, b, a0, b0; bool a_ok, b_ok;
+};
+__device__ __forceinline__ void sm_flush_load_c(const double* __restrict__ Cp, int lane, double (&cv0)[8], double (&cv1)[8]) {
     const int r = lane & 15, kk = lane >> 4;
-    const int a = min(a0 + r, n - 1), b = min(b0 + r, n - 1);          // clamped: loads stay unconditional
-    const bool a_ok = a0 + r < n, b_ok = b0 + r < n;
-    double av[8], bv[8], cv0[8], cv1[8], gv[4], gt[4];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) { const int mm = 4 * s + kk; cv0[s] = ld_coh(Cp + mm * SM_KD + r); cv1[s] = ld_coh(Cp + mm * SM_KD + 16 + r); }
+}
+__device__ __forceinline__ void sm_flush_load(SmFlushOps& o, const double* __restrict__ G, const double* __restrict__ GT, const double* __restrict__ Ap,
+                                              const double* __restrict__ Bp, int a0, int b0, int n, int lane) {
+    const int r = lane & 15, kk = lane >> 4;
+    o.a0 = a0; o.b0 = b0;
+    o.a = min(a0 + r, n - 1); o.b = min(b0 + r, n - 1);                // clamped: loads stay unconditional
+    o.a_ok = a0 + r < n; o.b_ok = b0 + r < n;
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
         const int mm = 4 * s + kk;                                     // window slot of this lane at k-step s
-        av[s] = ld_coh(Ap + mm * n + a); bv[s] = ld_coh(Bp + mm * n + b);
-        cv0[s] = ld_coh(Cp + mm * SM_KD + r); cv1[s] = ld_coh(Cp + mm * SM_KD + 16 + r);
+        o.av[s] = ld_coh(Ap + mm * n + o.a); o.bv[s] = ld_coh(Bp + mm * n + o.b);
     }
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
         const int bb = min(b0 + kk + 4 * reg, n - 1), aa = min(a0 + kk + 4 * reg, n - 1);
-        gv[reg] = ld_coh(G + a + (long)n * bb); gt[reg] = ld_coh(GT + b + (long)n * aa);
+        o.gv[reg] = ld_coh(G + o.a + (long)n * bb); o.gt[reg] = ld_coh(GT + o.b + (long)n * aa);
     }
-    if (k == 0) return;
+}
+__device__ __forceinline__ void sm_flush_apply(const SmFlushOps& o, const double (&cv0)[8], const double (&cv1)[8], double* __restrict__ G, double* __restrict__ GT,
+                                               int n, int k, int lane) {
+    const int kk = lane >> 4;
     d4 d1lo = {0.0, 0.0, 0.0, 0.0}, d1hi = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
         const bool ok = 4 * s + kk < k;                                // panel rows and C rows beyond k hold stale data
-        const double am = (ok && a_ok) ? av[s] : 0.0, c_lo = ok ? cv0[s] : 0.0, c_hi = ok ? cv1[s] : 0.0;
+        const double am = (ok && o.a_ok) ? o.av[s] : 0.0, c_lo = ok ? cv0[s] : 0.0, c_hi = ok ? cv1[s] : 0.0;
         d1lo = __builtin_amdgcn_mfma_f64_16x16x4f64(c_lo, am, d1lo, 0, 0, 0);       // rows <-> nn (0..15), columns <-> a
         d1hi = __builtin_amdgcn_mfma_f64_16x16x4f64(c_hi, am, d1hi, 0, 0, 0);       // rows <-> nn (16..31)
     }
@@ -354,16 +381,16 @@ __device__ __forceinline__ void sm_flush_tile(double* __restrict__ G, double* __
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
         const bool ok = 4 * s + kk < k;
-        const double bm = (ok && b_ok) ? bv[s] : 0.0;
+        const double bm = (ok && o.b_ok) ? o.bv[s] : 0.0;
         const double dm = s < 4 ? d1lo[s & 3] : d1hi[s & 3];           // D1[nn = 4 s + kk][a = r]
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(bm, dm, acc, 0, 0, 0);           // rows <-> b, columns <-> a
         acc_t = __builtin_amdgcn_mfma_f64_16x16x4f64(dm, bm, acc_t, 0, 0, 0);       // rows <-> a, columns <-> b
     }
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
-        const int bb = b0 + kk + 4 * reg, aa = a0 + kk + 4 * reg;
-        if (a_ok && bb < n) st_coh(G + a + (long)n * bb, gv[reg] + acc[reg]);
-        if (b_ok && aa < n) st_coh(GT + b + (long)n * aa, gt[reg] + acc_t[reg]);
+        const int bb = o.b0 + kk + 4 * reg, aa = o.a0 + kk + 4 * reg;
+        if (o.a_ok && bb < n) st_coh(G + o.a + (long)n * bb, o.gv[reg] + acc[reg]);
+        if (o.b_ok && aa < n) st_coh(GT + o.b + (long)n * aa, o.gt[reg] + acc_t[reg]);
     }
 }
 
@@ -372,7 +399,7 @@ __device__ __forceinline__ void sm_flush_tile(double* __restrict__ G, double* __
 // grid = (1 + Fwg, chains): workgroup 0 walks, workgroups 1 .. Fwg flush; flush workgroup f owns the 32 x 32 tiles f, f + Fwg, ...
 // of G and GT (one tile each while tiles^2 <= 192; two each at n = 576)
 template <int NS>
-__global__ __launch_bounds__(256) void slice_sm_kernel(UpdateDesc d, SliceSync* sync_p, int l, int acc_slot, int tiles_per_dim, int kd, int* info) {
+__global__ __launch_bounds__(256) void slice_sm_kernel(UpdateDesc d, SliceSync* sync_p, int l, int acc_slot, int tiles_per_dim, int* info) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int chain = blockIdx.y;
     const int n = d.n;
@@ -413,10 +440,16 @@ __global__ __launch_bounds__(256) void slice_sm_kernel(UpdateDesc d, SliceSync* 
             const int k = (int)(lo & 0x3fffffffu);
             const bool final = (lo & SLICE_FINAL_BIT) != 0;
             if (k > 0) {
-                for (int tile = (int)blockIdx.x - 1; tile < n_tiles; tile += F) {
-                    const int a0 = (tile % tiles_per_dim) * 32 + (wave & 1) * 16;
-                    const int b0 = (tile / tiles_per_dim) * 32 + (wave >> 1) * 16;
-                    if (a0 < n && b0 < n) sm_flush_tile(G, GT, Ap, Bp, Cp, a0, b0, n, k, lane);
+                double cv0[8], cv1[8];
+                sm_flush_load_c(Cp, lane, cv0, cv1);
+                for (int tile = (int)blockIdx.x - 1; tile < n_tiles; tile += 2 * F) {      // two tiles at a time
+                    const int tile2 = tile + F;                                            // (workgroup-uniform)
+                    SmFlushOps o1, o2;
+                    sm_flush_load(o1, G, GT, Ap, Bp, (tile % tiles_per_dim) * 32 + (wave & 1) * 16, (tile / tiles_per_dim) * 32 + (wave >> 1) * 16, n, lane);
+                    if (tile2 < n_tiles)
+                        sm_flush_load(o2, G, GT, Ap, Bp, (tile2 % tiles_per_dim) * 32 + (wave & 1) * 16, (tile2 / tiles_per_dim) * 32 + (wave >> 1) * 16, n, lane);
+                    if (o1.a0 < n && o1.b0 < n) sm_flush_apply(o1, cv0, cv1, G, GT, n, k, lane);
+                    if (tile2 < n_tiles && o2.a0 < n && o2.b0 < n) sm_flush_apply(o2, cv0, cv1, G, GT, n, k, lane);
                 }
             }
             if (final) break;
@@ -428,7 +461,7 @@ __global__ __launch_bounds__(256) void slice_sm_kernel(UpdateDesc d, SliceSync* 
     } else {
         // ================= walk role =================
         SmShared sh;
-        sm_shared_init(sh, smem, n, kd);
+        sm_shared_init(sh, smem, n);
         const double* tab_g = reinterpret_cast<const double*>(d.tabs + chain);
         const long slice_off = (long)l * n;
         int8_t* fields_g = d.fields + (long)chain * d.f_stride + slice_off;
@@ -439,7 +472,7 @@ __global__ __launch_bounds__(256) void slice_sm_kernel(UpdateDesc d, SliceSync* 
             const int i = d.perm[off];
             const int kp = d.kprop[off];
             const int old_f = fields_g[i];
-            sh.site[tt] = i; sh.newf[tt] = (signed char)c_proposal_sm[old_f][kp];
+            sh.site[tt] = i; sh.posof[i] = tt; sh.newf[tt] = (signed char)c_proposal_sm[old_f][kp];
             sh.rbv[tt] = tab_g[old_f * 3 + kp]; sh.dlt[tt] = tab_g[12 + old_f * 3 + kp]; sh.ur[tt] = d.u[off];
             sh.diag0[tt] = G[tt + (long)n * tt];                         // first window: G was written by the previous kernel
         }
@@ -485,7 +518,7 @@ __global__ __launch_bounds__(256) void slice_sm_kernel(UpdateDesc d, SliceSync* 
         bool broken = false;
         SMX(SmProf prof; unsigned long long tk0, t_hand = 0; SMT(tk0))
         for (unsigned win = 1;; ++win) {
-            const int k = sm_walk_window<NS>(sh, pos, n, kd, t, G, GT, d, slice_off, chain, fields_g, Ap, Bp, Cp, win > 1 SM_PROF_PASS);
+            const int k = sm_walk_window<NS>(sh, pos, n, t, G, GT, d, slice_off, chain, fields_g, Ap, Bp, Cp, win > 1 SM_PROF_PASS);
             total_acc += k;
             const bool final = pos >= n;
             SMX(unsigned long long th0; SMT(th0))
@@ -542,10 +575,10 @@ int slice_flush_workgroups(int n) {
 int launch_update_slice_sm(const UpdateDesc& d, int l, int acc_slot, int n_chains, hipStream_t s) {
     const int n = d.n;
     if (n > 1024 || !d.Cpanel || !d.slice_sync || !d.GT.p) { set_error("sub-matrix slice kernel: n <= 1024, panel / sync / transposed workspaces required"); return -1; }
-    const int tiles = (n + 31) / 32, kd = sm_pick_kd(n);
+    const int tiles = (n + 31) / 32;
     const dim3 grid(1 + slice_flush_workgroups(n), n_chains), block(256);
-    const size_t lds = sm_lds_bytes(n, kd);
-#define SM_LAUNCH(NS) hipLaunchKernelGGL((slice_sm_kernel<NS>), grid, block, lds, s, d, reinterpret_cast<SliceSync*>(d.slice_sync), l, acc_slot, tiles, kd, d.info)
+    const size_t lds = sm_lds_bytes(n);
+#define SM_LAUNCH(NS) hipLaunchKernelGGL((slice_sm_kernel<NS>), grid, block, lds, s, d, reinterpret_cast<SliceSync*>(d.slice_sync), l, acc_slot, tiles, d.info)
     if (n <= 256) SM_LAUNCH(1); else if (n <= 512) SM_LAUNCH(2); else if (n <= 768) SM_LAUNCH(3); else SM_LAUNCH(4);
 #undef SM_LAUNCH
     DQ_HIP(hipGetLastError());
