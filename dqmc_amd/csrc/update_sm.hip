@@ -150,6 +150,33 @@ __device__ __forceinline__ void sm_shared_init(SmShared& sh, unsigned char* smem
         "v_fmac_f64_dpp %3, %4, %5 row_newbcast:" #R3 " row_mask:0xf bank_mask:0xf"                                 \
         : "+v"(M[MB]), "+v"(M[MB + 1]), "+v"(M[MB + 2]), "+v"(M[MB + 3])                                            \
         : "v"(pv), "v"(x))
+// the two products of a pass, y = C beta and z = C^T alpha, interleaved: four independent accumulator chains, a dependent fp64 FMA only every
+// fourth instruction (the z product used to follow the decision, on the accepted path: ~300 clk of dependent chain per accepted flip)
+#define SM_DOT4X2(R0, R1, R2, R3, ya, yb, za, zb, pvy, pvz, M, N, MB)                                               \
+    asm("s_nop 1\n\t"                                                                                               \
+        "v_fmac_f64_dpp %0, %4, %6 row_newbcast:" #R0 " row_mask:0xf bank_mask:0xf\n\t"                             \
+        "v_fmac_f64_dpp %1, %4, %7 row_newbcast:" #R1 " row_mask:0xf bank_mask:0xf\n\t"                             \
+        "v_fmac_f64_dpp %2, %5, %10 row_newbcast:" #R0 " row_mask:0xf bank_mask:0xf\n\t"                            \
+        "v_fmac_f64_dpp %3, %5, %11 row_newbcast:" #R1 " row_mask:0xf bank_mask:0xf\n\t"                            \
+        "v_fmac_f64_dpp %0, %4, %8 row_newbcast:" #R2 " row_mask:0xf bank_mask:0xf\n\t"                             \
+        "v_fmac_f64_dpp %1, %4, %9 row_newbcast:" #R3 " row_mask:0xf bank_mask:0xf\n\t"                             \
+        "v_fmac_f64_dpp %2, %5, %12 row_newbcast:" #R2 " row_mask:0xf bank_mask:0xf\n\t"                            \
+        "v_fmac_f64_dpp %3, %5, %13 row_newbcast:" #R3 " row_mask:0xf bank_mask:0xf"                                  \
+        : "+v"(ya), "+v"(yb), "+v"(za), "+v"(zb)                                                                    \
+        : "v"(pvy), "v"(pvz), "v"(M[MB]), "v"(M[MB + 1]), "v"(M[MB + 2]), "v"(M[MB + 3]),                           \
+          "v"(N[MB]), "v"(N[MB + 1]), "v"(N[MB + 2]), "v"(N[MB + 3]))
+#define SM_DOT8X2LO(ya, yb, za, zb, pvy, pvz, M, N) SM_DOT4X2(0, 1, 2, 3, ya, yb, za, zb, pvy, pvz, M, N, 0); SM_DOT4X2(4, 5, 6, 7, ya, yb, za, zb, pvy, pvz, M, N, 4)
+#define SM_DOT8X2HI(ya, yb, za, zb, pvy, pvz, M, N) SM_DOT4X2(8, 9, 10, 11, ya, yb, za, zb, pvy, pvz, M, N, 8); SM_DOT4X2(12, 13, 14, 15, ya, yb, za, zb, pvy, pvz, M, N, 12)
+// y = C v, z = C^T w over the first k columns: rows in (c0 | c1) and (t0 | t1), v broadcast from (va, vb), w from (wa_, wb_)
+#define SM_MATVEC2(outy, outz, va, vb, wa_, wb_)                                                                    \
+    {                                                                                                               \
+        double y0_ = 0.0, y1_ = 0.0, z0_ = 0.0, z1_ = 0.0;                                                          \
+        if (k > 0) { SM_DOT8X2LO(y0_, y1_, z0_, z1_, va, wa_, c0, t0); }                                            \
+        if (k > 8) { SM_DOT8X2HI(y0_, y1_, z0_, z1_, va, wa_, c0, t0); }                                            \
+        if (k > 16) { SM_DOT8X2LO(y0_, y1_, z0_, z1_, vb, wb_, c1, t1); }                                           \
+        if (k > 24) { SM_DOT8X2HI(y0_, y1_, z0_, z1_, vb, wb_, c1, t1); }                                           \
+        outy = y0_ + y1_; outz = z0_ + z1_;                                                                         \
+    }
 #define SM_DOT16(acc_a, acc_b, pv, M)                                                                               \
     SM_DOT4(0, 1, 2, 3, acc_a, acc_b, pv, M, 0); SM_DOT4(4, 5, 6, 7, acc_a, acc_b, pv, M, 4);                       \
     SM_DOT4(8, 9, 10, 11, acc_a, acc_b, pv, M, 8); SM_DOT4(12, 13, 14, 15, acc_a, acc_b, pv, M, 12)
@@ -255,8 +282,8 @@ __device__ __forceinline__ int sm_walk_window(const SmShared& sh, int& pos, int 
             if (r16 >= k) { be_a = 0.0; al_a = 0.0; }                                                                                    \
             if (16 + r16 >= k) { be_b = 0.0; al_b = 0.0; }                                                                               \
             const double al_m = (lane & 16) ? al_b : al_a;                   /* alpha_m, m = lane & 31 */                                 \
-            double y;                                                                                                                    \
-            SM_MATVEC(y, c0, c1, be_a, be_b)                                 /* y_m = sum_n C[m][n] beta_n */                            \
+            double y, z;                                                     /* y_m = sum_n C[m][n] beta_n, z_m = sum_n C[n][m] alpha_n */ \
+            SM_MATVEC2(y, z, be_a, be_b, al_a, al_b)                                                                                     \
             double s = al_m * y;                                                                                                         \
             s = row16_sum(s);                                                                                                            \
             s += dpp_mov_f64<0x142, 0xa>(s);                                 /* row_bcast:15: rows 1 and 3 hold the sums of their halves */ \
@@ -273,9 +300,14 @@ __device__ __forceinline__ int sm_walk_window(const SmShared& sh, int& pos, int 
             const int first = p - g * 8;                                                                                                 \
             pos = p + 1;                                                                                                                 \
             const int i = __builtin_amdgcn_readlane(jme, hx * 32 + 31);                                                                  \
-            const double pref = readlane_f64(dl, hx * 32 + 31) / readlane_f64(r, hx * 32 + 31);   /* source/model.cpp:132 */              \
-            double z;                                                                                                                    \
-            SM_MATVEC(z, t0, t1, al_a, al_b)                                 /* z_m = sum_n C[n][m] alpha_n */                           \
+            /* delta / r (source/model.cpp:132) by v_rcp_f64 + two Newton steps and a residual correction: an ulp or two from the IEEE quotient, */ \
+            /* a fifth of its ~250 clk on the accepted path */                                                                           \
+            const double rr_ = readlane_f64(r, hx * 32 + 31), dd_ = readlane_f64(dl, hx * 32 + 31);                                      \
+            double ir_ = __builtin_amdgcn_rcp(rr_);                                                                                      \
+            ir_ = fma(fma(-rr_, ir_, 1.0), ir_, ir_);                                                                                    \
+            ir_ = fma(fma(-rr_, ir_, 1.0), ir_, ir_);                                                                                    \
+            double pref = dd_ * ir_;                                                                                                     \
+            pref = fma(fma(-rr_, pref, dd_), ir_, pref);                                                                                 \
             /* u~ = [y; 1], w~ = [z; 1] of the accepted half, into the broadcast layout of every row */                                  \
             const int src = hx * 32 + r16;                                                                                               \
             double ua = shfl_f64(y, src), ub = shfl_f64(y, src + 16), wa = shfl_f64(z, src), wb = shfl_f64(z, src + 16);                 \
