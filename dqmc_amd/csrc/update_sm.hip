@@ -58,16 +58,29 @@ __device__ __forceinline__ double ld_coh(const double* p) {
 __device__ __forceinline__ void st_coh(double* p, double x) {
     __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// The same store as st_coh, written as inline asm: the panel stores of an accepted flip sit inside the walk's pass loop, and a loop with
+// VMEM stores and no VMEM loads makes the compiler's wait-count pass flush vmcnt in the loop preheader (SIInsertWaitcnts, "flush in
+// preheader") -- right after the next group's prefetch has been issued: a full memory round trip per group of 8 proposals (~150 us of a
+// 665 us cfg-5 slice).  Stores the pass does not see only make its later vmcnt(N) waits stricter than needed (the counter retires in
+// order), never unsafe; the window end drains them with an explicit s_waitcnt vmcnt(0) before the hand-off word is published.
+__device__ __forceinline__ void st_coh_opaque(double* p, double x) {
+    asm volatile("global_store_dwordx2 %0, %1, off sc1" : : "v"(p), "v"(x) : "memory");
+}
 __device__ __forceinline__ void lds_barrier() {              // orders LDS traffic only (no vmcnt(0): the prefetch stays in flight)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 }
-__device__ __forceinline__ double shfl_f64(double x, int src_lane) {
-    const long long b = __double_as_longlong(x);
-    const int lo = __builtin_amdgcn_ds_bpermute(src_lane << 2, (int)(b & 0xffffffffLL));
-    const int hi = __builtin_amdgcn_ds_bpermute(src_lane << 2, (int)(b >> 32));
-    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+// rows 2 hx and 2 hx + 1 (16 lanes each) of x replicated into all four rows of the wave: ra <- row 2 hx, rb <- row 2 hx + 1 (hx wave-uniform).
+// gfx950 v_permlane32_swap / v_permlane16_swap, two VALU instructions per dword, instead of ds_bpermute through the LDS crossbar.
+__device__ __forceinline__ void sm_bcast_rows(double x, int hx, double& ra, double& rb) {
+    const unsigned lo = (unsigned)__double_as_longlong(x), hi = (unsigned)(__double_as_longlong(x) >> 32);
+    const auto l32 = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);       // [0]: lower half in both halves, [1]: upper half
+    const auto h32 = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    const unsigned vlo = hx ? l32[1] : l32[0], vhi = hx ? h32[1] : h32[0];
+    const auto l16 = __builtin_amdgcn_permlane16_swap(vlo, vlo, false, false);     // [0]: even row of each pair in both, [1]: odd row
+    const auto h16 = __builtin_amdgcn_permlane16_swap(vhi, vhi, false, false);
+    ra = __hiloint2double((int)h16[0], (int)l16[0]); rb = __hiloint2double((int)h16[1], (int)l16[1]);
 }
 
 struct SmShared {
@@ -262,7 +275,7 @@ __device__ __forceinline__ int sm_walk_window(const SmShared& sh, int& pos, int 
     if (t + 256 * sl < n) {                                                                                                              \
         const double cv_ = gc##sl, rv_ = (t + 256 * sl == i) ? gr##sl - 1.0 : gr##sl;                                                    \
         if (q##sl >= 0) { cols[k * LS + q##sl] = cv_; rows[k * LS + q##sl] = rv_; }                                                      \
-        st_coh(Ap + k * n + t + 256 * sl, cv_); st_coh(Bp + k * n + t + 256 * sl, rv_);                                                  \
+        st_coh_opaque(Ap + k * n + t + 256 * sl, cv_); st_coh_opaque(Bp + k * n + t + 256 * sl, rv_);                                                  \
     }
 #define SM_GROUP(PCS, PRS, PCT, PRT)                                                                                                     \
     {                                                                                                                                    \
@@ -309,8 +322,8 @@ __device__ __forceinline__ int sm_walk_window(const SmShared& sh, int& pos, int 
             double pref = dd_ * ir_;                                                                                                     \
             pref = fma(fma(-rr_, pref, dd_), ir_, pref);                                                                                 \
             /* u~ = [y; 1], w~ = [z; 1] of the accepted half, into the broadcast layout of every row */                                  \
-            const int src = hx * 32 + r16;                                                                                               \
-            double ua = shfl_f64(y, src), ub = shfl_f64(y, src + 16), wa = shfl_f64(z, src), wb = shfl_f64(z, src + 16);                 \
+            double ua, ub, wa, wb;                                                                                                       \
+            sm_bcast_rows(y, hx, ua, ub); sm_bcast_rows(z, hx, wa, wb);                                                                  \
             if (r16 == (k & 15)) { if (k < 16) { ua = 1.0; wa = 1.0; } else { ub = 1.0; wb = 1.0; } }                                    \
             const double pu = pref * ((lane & 16) ? ub : ua), pw = pref * ((lane & 16) ? wb : wa);                                       \
             /* C[m][n] += pref u~_m w~_n,  C^T[m][n] += pref w~_m u~_n  for n <= k */                                                    \
