@@ -211,7 +211,7 @@ __device__ __forceinline__ void sm_shared_init(SmShared& sh, unsigned char* smem
 
 #ifdef DQ_SM_STAMPS
 #define SMT(v) { unsigned long long _t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t) :: "memory"); v = _t; }
-struct SmProf { unsigned long long t_pass = 0, t_acc = 0, t_dump = 0, t_hand = 0, t_first = 0; int n_pass = 0, n_acc = 0; };
+struct SmProf { unsigned long long t_pass = 0, t_acc = 0, t_dump = 0, t_hand = 0, t_first = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0; int n_pass = 0, n_acc = 0; };
 #define SM_PROF_ARG , SmProf& prof
 #define SM_PROF_PASS , prof
 #define SMX(...) __VA_ARGS__
@@ -321,6 +321,7 @@ __device__ __forceinline__ int sm_walk_window(const SmShared& sh, int& pos, int 
             ir_ = fma(fma(-rr_, ir_, 1.0), ir_, ir_);                                                                                    \
             double pref = dd_ * ir_;                                                                                                     \
             pref = fma(fma(-rr_, pref, dd_), ir_, pref);                                                                                 \
+            SMX(unsigned long long ta1_, ta2_, ta3_; SMT(ta1_) prof.a1 += ta1_ - t1_;)                                                   \
             /* u~ = [y; 1], w~ = [z; 1] of the accepted half, into the broadcast layout of every row */                                  \
             double ua, ub, wa, wb;                                                                                                       \
             sm_bcast_rows(y, hx, ua, ub); sm_bcast_rows(z, hx, wa, wb);                                                                  \
@@ -331,15 +332,17 @@ __device__ __forceinline__ int sm_walk_window(const SmShared& sh, int& pos, int 
             if (k >= 8) { SM_AXPY8HI(c0, wa, pu); SM_AXPY8HI(t0, ua, pw); }                                                              \
             if (k >= 16) { SM_AXPY8LO(c1, wb, pu); SM_AXPY8LO(t1, ub, pw); }                                                             \
             if (k >= 24) { SM_AXPY8HI(c1, wb, pu); SM_AXPY8HI(t1, ub, pw); }                                                             \
+            SMX(asm volatile("" :: "v"(c0[0]), "v"(t0[0])); SMT(ta2_) prof.a2 += ta2_ - ta1_;)                                           \
             /* slot k of A^T / B^T: the column and the row of G0 at the flipped site, every thread its own element */                   \
             double gc0, gr0, gc1, gr1, gc2, gr2, gc3, gr3;                                                                               \
             SM_PICK8(PCS, PRS)                                                                                                           \
             /* V(i) -= 1 (source/model.cpp:135).  LDS: the sites still to come, by position; memory: the whole column / row, the flush's operands */ \
             SM_SLOT(0) if constexpr (NS > 1) SM_SLOT(1) if constexpr (NS > 2) SM_SLOT(2) if constexpr (NS > 3) SM_SLOT(3)                \
+            SMX(SMT(ta3_) prof.a3 += ta3_ - ta2_;)                                                                                       \
             if (t == 0) sh.acc_site[k] = p;                                                                                              \
             ++k;                                                                                                                         \
             lds_barrier();                                                                                                               \
-            SMX(SMT(t2_) prof.t_acc += t2_ - t1_; prof.n_acc++;)                                                                         \
+            SMX(SMT(t2_) prof.t_acc += t2_ - t1_; prof.a4 += t2_ - ta3_; prof.n_acc++;)                                                  \
             if (k >= kd) { done = true; break; }                                                                                      \
         }                                                                                                                                \
         if (pos >= n) done = true;                                                                                                       \
@@ -594,8 +597,8 @@ __global__ __launch_bounds__(256) void slice_sm_kernel(UpdateDesc d, SliceSync* 
         }
         if (t == 0) d.acc_out[(long)chain * d.acc_stride + acc_slot] = total_acc;
         SMX(if (t == 0) { unsigned long long tk1; SMT(tk1)
-            printf("sm slice l=%d: total %llu cyc | windows (walk incl. passes+accepts) %llu | %d passes %llu | %d accepts %llu | dump %llu | hand-offs %llu\n",
-                   l, tk1 - tk0, prof.t_first, prof.n_pass, prof.t_pass, prof.n_acc, prof.t_acc, prof.t_dump, t_hand); })
+            printf("sm slice l=%d: total %llu cyc | windows (walk incl. passes+accepts) %llu | %d passes %llu | %d accepts %llu (pref %llu, bcast + axpy %llu, pick + panel writes %llu, barrier %llu) | dump %llu | hand-offs %llu\n",
+                   l, tk1 - tk0, prof.t_first, prof.n_pass, prof.t_pass, prof.n_acc, prof.t_acc, prof.a1, prof.a2, prof.a3, prof.a4, prof.t_dump, t_hand); })
     }
 }
 
