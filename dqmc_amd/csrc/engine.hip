@@ -68,7 +68,7 @@ struct Ctx {
     int* qpivpos = nullptr;                    // ... and its pivot positions: n * C
     double* trinv = nullptr;                   // blocked triangular solve: inverses of the 16 x 16 diagonal blocks, 16 * (n + 16) * C
     bool use_tri = false;                      // R^-1 D by tri_solve.hip (n <= 640; the per-column substitution of lu.hip above that)
-    bool use_gj = false;                       // n <= 256, few chains: solves go through lu_gj.hip (DQMC_LU_CLASSIC=1 keeps dgetrf + dgetrs)
+    bool use_gj = false;                       // n <= 1024, few chains: solves go through lu_gj.hip (DQMC_LU_CLASSIC=1 keeps dgetrf + dgetrs)
 
     Mat T(int k) const { return Mat{pool + (long)k * C * nn, nn}; }
     Vec V(int k) const { return Vec{vpool + (long)k * C * n, (long)n}; }
@@ -100,7 +100,7 @@ struct Ctx {
         // latency regime only: with many chains per launch the blocked LU + per-column substitution has the higher throughput
         // (128 chains, cfg 3: 458 ms per step against 483 ms with the single-wave panels)
         const int gj_max_chains = getenv("DQMC_GJ_MAX_CHAINS") ? atoi(getenv("DQMC_GJ_MAX_CHAINS")) : 8;
-        const int gj_max_n = getenv("DQMC_GJ_MAX_N") ? atoi(getenv("DQMC_GJ_MAX_N")) : 640;      // A/B switch (256: blocked LU above; beyond 640 the 16-wave panel spills 12 VGPRs)
+        const int gj_max_n = getenv("DQMC_GJ_MAX_N") ? atoi(getenv("DQMC_GJ_MAX_N")) : 1024;     // test switch (256: blocked LU above); n = 704 ... 1024: 8.4 / 11.7 / 12.0 ms per inv(I + F1 F2) call against 9.9 / 14.0 / 14.1 with the blocked LU
         use_gj = n <= gj_max_n && n <= 1024 && C <= gj_max_chains && getenv("DQMC_LU_CLASSIC") == nullptr;
         DQ_HIP(hipMemsetAsync(ipool, 0, sizeof(int) * (3L * C * n + 4), stream));
         return 0;

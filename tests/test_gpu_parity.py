@@ -368,7 +368,7 @@ def test_cfg3_one_block_then_properties(hip, orc):
 
 def test_cfg5_size_streaming_kernels(hip, orc):
     """cfg 5 (24x24, beta=10, Ltau=400, n_stab=10): N = 576 takes the cooperative multi-workgroup QRCP (qr_coop.hip), the
-    LDS-staged 32x32-tile GEMM, the Gauss-Jordan solve with the 10-wave panel and the persistent sub-matrix slice kernel
+    LDS-staged 32x32-tile GEMM, the Gauss-Jordan solve with three rows per lane in its panel and the persistent sub-matrix slice kernel
     (update_sm.hip).  The oracle (LAPACK back end when present, for speed) checks G(0,0) / log det from scratch and one
     stabilisation block of the forward sweep."""
     m = HubbardModel(**CONFIGS["cfg5"]); f = m.random_fields(55)
@@ -425,7 +425,7 @@ def test_batched_engine(hip, orc):
 @pytest.mark.parametrize("L1,L2,C", [(10, 10, 3), (20, 20, 2), (17, 17, 2)])
 def test_batched_engine_at_ragged_and_large_sizes(hip, orc, L1, L2, C):
     """Few chains per engine at N = 100 (not a multiple of 16: partial blocks in the blocked triangular solve and the Gauss-Jordan
-    panels), N = 400 and N = 289 (batched LDS-staged GEMM with a ragged last stage, 10-wave Gauss-Jordan panels, cooperative QRCP
+    panels), N = 400 and N = 289 (batched LDS-staged GEMM with a ragged last stage, two-rows-per-lane Gauss-Jordan panels, cooperative QRCP
     for two matrices at once): G after initialisation and after a half sweep, fields and accepted counts, per chain against the oracle."""
     m = HubbardModel(L1=L1, L2=L2, U=4.0, beta=1.0, nt=10, n_stab=5)
     f = np.stack([m.random_fields(40 + c) for c in range(C)])
@@ -1067,7 +1067,8 @@ def test_mid_sizes_between_the_named_configs(hip, orc, L1, L2):
 def test_large_lattices_submatrix_walk_and_cooperative_qrcp(hip, orc, L1, L2):
     """256 < N <= 1024 (N = 320, 289, 576, 525, 896: two, three and four site slots per thread; 289 and 525 are multiples of neither
     16 nor 32: partial MFMA tiles in the flushes, padding rows and a short last workgroup in the QRCP): the persistent sub-matrix slice kernel
-    (update_sm.hip, windows of 31 / 15 / 8 flips, flush workgroups owning several tiles) and the cooperative QRCP (qr_coop.hip)
+    (update_sm.hip, windows growing from 31 / 15 / 8 flips to 32 as the sites still to visit get fewer, flush workgroups owning several tiles;
+    N = 896: the Gauss-Jordan panel with two rows per lane on eight waves) and the cooperative QRCP (qr_coop.hip)
     against the oracle (LAPACK back end when present, for speed): exact fields and accepted counts, G to 1e-10 * max|G| after each
     half sweep, log det, wrap errors of the same size."""
     m = HubbardModel(L1=L1, L2=L2, U=4.0, beta=1.0, nt=12 if L1 == 17 else 10, n_stab=5); f = m.random_fields(77)   # nt = 12: a short last block too
