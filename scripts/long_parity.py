@@ -2,6 +2,7 @@
 (both of its dense back ends, one after the other: the back end is a process-wide switch) with the same random stream.  After EVERY
 sweep: are the HS fields identical, max|dG| GPU vs oracle (LAPACK back end) beside the CPU-vs-CPU difference of the two back ends on the
 same sweep, and max|G| (the 1e-10 bar is absolute on the fixture's O(10) entries; along a trajectory max|G(0,0)| wanders up to 1e3).
+A configuration without a thermalised fixture (cfg 5) starts from i.i.d. fields and compares against the LAPACK back end only.
 usage: long_parity.py [sweeps] [cfg]      (DQMC_QR_PANEL=0 for the column-pivoted to_LDR)"""
 import os, sys, time
 import numpy as np
@@ -12,7 +13,10 @@ from dqmc_amd import fixtures
 from oracle import oracle
 nsw = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 cfg = sys.argv[2] if len(sys.argv) > 2 else "cfg3"
-z, m, _ = fixtures.load(cfg + "_therm")
+if cfg + "_therm" in fixtures.NAMES:
+    z, m, _ = fixtures.load(cfg + "_therm"); both_backends = True
+else:
+    m = dqmc_amd.HubbardModel(**dqmc_amd.CONFIGS[cfg]); z = {"fields": m.random_fields(55)}; both_backends = False
 hip = dqmc_amd.lib(); orc = oracle()
 rng = np.random.default_rng(4242)
 streams = [(m.random_stream(rng), m.random_stream(rng)) for _ in range(nsw)]
@@ -31,7 +35,7 @@ def run(lib):
 t0 = time.time()
 have_lapack = orc.set_backend("lapack")
 ref = run(orc)
-orc.set_backend("builtin"); ref2 = run(orc) if have_lapack else ref
+orc.set_backend("builtin"); ref2 = run(orc) if (have_lapack and both_backends) else ref
 gpu = run(hip)
 worst_abs = worst_rel = 0.0
 for sw in range(nsw):
