@@ -302,6 +302,14 @@ __device__ __forceinline__ int sm_walk_window(const SmShared& sh, int& pos, int 
             s += dpp_mov_f64<0x142, 0xa>(s);                                 /* row_bcast:15: rows 1 and 3 hold the sums of their halves */ \
             const double gjj = d0 + s;                                       /* G_k[j, j] */                                              \
             const double r = 1.0 + (1.0 - gjj) * dl;                         /* det ratio per flavour (source/model.cpp:95) */            \
+            /* delta / r (source/model.cpp:132), needed only if the proposal is accepted, formed here next to the decision: v_rcp_f64 + two Newton */ \
+            /* steps and a residual correction (an ulp or two from the IEEE quotient) -- eight operations that issue under the latency of the */ \
+            /* decision's own chain instead of ~350 clk of dependent chain on the accepted path */                                        \
+            double ir_ = __builtin_amdgcn_rcp(r);                                                                                        \
+            ir_ = fma(fma(-r, ir_, 1.0), ir_, ir_);                                                                                      \
+            ir_ = fma(fma(-r, ir_, 1.0), ir_, ir_);                                                                                      \
+            double prf_ = dl * ir_;                                                                                                      \
+            prf_ = fma(fma(-r, prf_, dl), ir_, prf_);                                                                                    \
             const double R = rb * (r * r);                                   /* :121 */                                                  \
             const bool acc_l = uu < fmin(1.0, fabs(R));                      /* bernoulli(min(1,|R|)): u < p (source/update.cpp:24) */    \
             const unsigned long long bal = __ballot(acc_l);                                                                              \
@@ -313,14 +321,7 @@ __device__ __forceinline__ int sm_walk_window(const SmShared& sh, int& pos, int 
             const int first = p - g * 8;                                                                                                 \
             pos = p + 1;                                                                                                                 \
             const int i = __builtin_amdgcn_readlane(jme, hx * 32 + 31);                                                                  \
-            /* delta / r (source/model.cpp:132) by v_rcp_f64 + two Newton steps and a residual correction: an ulp or two from the IEEE quotient, */ \
-            /* a fifth of its ~250 clk on the accepted path */                                                                           \
-            const double rr_ = readlane_f64(r, hx * 32 + 31), dd_ = readlane_f64(dl, hx * 32 + 31);                                      \
-            double ir_ = __builtin_amdgcn_rcp(rr_);                                                                                      \
-            ir_ = fma(fma(-rr_, ir_, 1.0), ir_, ir_);                                                                                    \
-            ir_ = fma(fma(-rr_, ir_, 1.0), ir_, ir_);                                                                                    \
-            double pref = dd_ * ir_;                                                                                                     \
-            pref = fma(fma(-rr_, pref, dd_), ir_, pref);                                                                                 \
+            const double pref = readlane_f64(prf_, hx * 32 + 31);                                                                        \
             SMX(unsigned long long ta1_, ta2_, ta3_; SMT(ta1_) prof.a1 += ta1_ - t1_;)                                                   \
             /* u~ = [y; 1], w~ = [z; 1] of the accepted half, into the broadcast layout of every row */                                  \
             double ua, ub, wa, wb;                                                                                                       \
