@@ -1,10 +1,11 @@
-// lu_gj.hip -- X = A^-1 B for n <= 256 (the arma::solve(M, RHS) of
+// lu_gj.hip -- X = A^-1 B for n <= 1024 (the arma::solve(M, RHS) of
 // stablelinalg::inv_I_plus_ldr_mul_ldr / inv_invldr_plus_ldr / inv_I_plus_ldr,
 // source/stablelinalg.cpp:122-125,153-155,184-186) as a blocked Gauss-Jordan
 // elimination with partial pivoting, two launches per panel of 32 columns and
 // no substitution phase at all:
 //
-//   gj_panel_kernel   ONE wave per chain.  Lane owns rows lane, lane+64, ... of the panel in
+//   gj_panel_kernel   (n <= 64; gj_panel_mw_kernel<NW, RPL> above that: NW waves x RPL rows per lane, one LDS barrier per step, see there)
+//                     ONE wave per chain.  Lane owns rows lane, lane+64, ... of the panel in
 //                     registers and runs dgetf2 on the live rows (pivot search = per-lane max +
 //                     32-bit DPP wave maxima + ballot, pivot row broadcast by v_readlane into
 //                     SGPRs: no LDS, no barrier, no memory access in the step loop).  A is NOT

@@ -21,16 +21,19 @@
 // is the reference's; only the rounding order differs (1e-14 against the sequential rank-1 form, tests/test_oracle.py).
 //
 // Walk workgroup (256 threads, one wave per SIMD, thread t <-> sites t, t + 256, ... : NS = ceil(n / 256) site slots):
-//   * LDS holds A^T and B^T of the window: cols[m][t] = G0[t, s_m], rows[m][t] = G0[s_m, t] - [t == s_m], written by
-//     all threads when flip m is accepted from the column / row elements every thread prefetches for every proposal
-//     (as in the delayed-update walk; G0 does not change inside a window, so the prefetch is exact);
+//   * LDS holds A^T and B^T of the window, restricted to the sites STILL TO BE VISITED and indexed by visiting position:
+//     cols[m][q] = G0[site(pos0 + q), s_m], rows[m][q] = G0[s_m, site(pos0 + q)] - [..], written by all threads when flip m
+//     is accepted from the column / row elements every thread prefetches for every proposal (as in the delayed-update
+//     walk; G0 does not change inside a window, so the prefetch is exact).  A window that starts later in the slice
+//     needs fewer columns and holds more flips (struct SmShared below);
 //   * every wave keeps its own copy of C and C^T in registers (lane m of each 32-lane half holds row m) and evaluates
-//     the SAME two proposals per pass (half 0: proposal pos, half 1: proposal pos + 1): y = C beta with the beta_n
-//     broadcast by the DPP network (v_fmac_f64_dpp row_newbcast), alpha^T y by a DPP reduction over the half.  All
+//     the SAME two proposals per pass (half 0: proposal pos, half 1: proposal pos + 1): y = C beta and z = C^T alpha with
+//     the operands broadcast by the DPP network (v_fmac_f64_dpp row_newbcast), alpha^T y by a DPP reduction over the half.  All
 //     waves take identical decisions, so the only synchronisation is one LDS barrier per accepted flip (the cols / rows
 //     slot of the flip must be complete before the next pass reads it);
-//   * nothing is stored to memory inside a window; at its end A^T, B^T (from LDS) and C go to the panel buffers.
-// Flush workgroups (one 32 x 32 tile of G and of its transposed copy GT each, one 16 x 16 sub-tile per wave):
+//   * the full column / row of an accepted flip (the flush's operands A^T, B^T) go to the panel buffers when the flip is
+//     accepted (st_coh_opaque), C at the window's end; nothing else is stored to memory inside a window.
+// Flush workgroups (one or two 32 x 32 tiles of G and of its transposed copy GT each, one 16 x 16 sub-tile per wave):
 //   D1 = C^T A^T (matrix cores), whose accumulator registers are directly the operands of the two final chains
 //   G_tile += D1^T B^T and GT_tile += B D1 (an MFMA D tile is the next product's A / B operand without a shuffle).
 // Hand-off protocol: the one of slice_kernel in update.hip (tagged window word, arrival counter, exit ticket).
